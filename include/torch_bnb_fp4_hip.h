@@ -1,0 +1,105 @@
+/*
+ * torch_bnb_fp4_hip.h -- C ABI of libtorch_bnb_fp4_hip.so, the MI355X (gfx950) FP4
+ * dequant / fused-GEMV kernels.
+ *
+ * This is the drop-in boundary of the hot path: plain pointers and sizes, no torch
+ * types.  Every pointer is a DEVICE pointer valid on the HIP device that is current
+ * on the calling thread; `stream` is a hipStream_t (NULL = the null stream).  All
+ * entry points are asynchronous (they enqueue on `stream` and return), stateless and
+ * re-entrant.  Return value: 0 on success, otherwise an fp4_status code;
+ * fp4_hip_last_error() then holds a thread-local message.  Nothing here allocates
+ * or synchronises, so every call is HIP-graph capturable.
+ *
+ * Each entry point names the reference interface it replaces
+ * (aredden/torch-bnb-fp4, paths relative to that checkout).  The reference has no
+ * C ABI of its own -- its boundary is the pybind module csrc/torch_fp4.cpp:125-139,
+ * which torch-bnb-fp4_amd/csrc/torch_ext.cpp re-exports 1:1 on top of this header
+ * (see INTEGRATION.md for the binding a reference maintainer would add).
+ */
+#ifndef TORCH_BNB_FP4_HIP_H
+#define TORCH_BNB_FP4_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FP4_HIP_ABI_VERSION 1
+#define FP4_HIP_API __attribute__((visibility("default")))
+
+/* Element types, numbered like the reference's ScalarTypeEnum (csrc/torch_fp4.cpp:22-26). */
+enum fp4_dtype { FP4_DTYPE_F16 = 0, FP4_DTYPE_F32 = 1, FP4_DTYPE_BF16 = 2 };
+
+/* Which 16-entry code table a dequant uses.
+ * CODEBOOK = the CODE_PARAM literals (csrc/dequant_fp4_optimized.cu:28-46),
+ * TREE     = the constants of dequantize_fp4_tree (csrc/dequant_fp4_optimized.cu:55-76);
+ * they differ by 1-12 ulp in f32 for nibbles 1,4,6 (and 9,12,14). */
+enum fp4_table { FP4_TABLE_CODEBOOK = 0, FP4_TABLE_TREE = 1 };
+
+enum fp4_status {
+    FP4_OK = 0,
+    FP4_ERR_INVALID_ARGUMENT = 1, /* null pointer, negative size, unknown enum */
+    FP4_ERR_UNSUPPORTED = 2,      /* shape/blocksize the kernels do not cover */
+    FP4_ERR_LAUNCH = 3            /* hipGetLastError() != hipSuccess after the launch */
+};
+
+FP4_HIP_API int fp4_hip_abi_version(void);
+FP4_HIP_API const char *fp4_hip_last_error(void);
+
+/* Host-side copy of a code table (16 floats; nibble bit 3 = sign). */
+FP4_HIP_API int fp4_hip_code_table(int table, float out16[16]);
+
+/*
+ * Blockwise FP4 -> f16 / bf16 / f32 dequant of n elements:
+ *   out[e] = RN_T( f32(code[nibble(e)]) * absmax[e / blocksize] ),  0 <= e < n,
+ * nibble(e) = HIGH nibble of packed[e/2] when e is even, LOW nibble when odd.
+ * One f32 multiply, then round-to-nearest-even to T (f16 subnormals kept).
+ *   packed : uint8[(n+1)/2]      absmax : float[ceil(n/blocksize)]      out : T[n]
+ * blocksize: any even value >= 2 (power-of-two >= 32 takes the fast path).
+ * Replaces dequantize_blockwise_fp4 (table = TREE, csrc/dequant_fp4_optimized.cu:182-205,
+ * kernel :89-123) and dequantize_blockwise_codebook_fp4 (table = CODEBOOK, :207-255,
+ * kernel :125-171).  Unlike the reference an unsupported dtype is an error, not a
+ * printf (:201-203,250-252).
+ */
+FP4_HIP_API int fp4_hip_dequantize_blockwise(const uint8_t *packed, const float *absmax, void *out, int blocksize, int64_t n,
+                                 int out_dtype, int table, void *stream);
+
+/*
+ * Fused batch-1 GEMV over an FP4 weight W[M,K] (row r = packed bytes [r*K/2, (r+1)*K/2),
+ * scales absmax[(r*K + k) / blocksize]):
+ *   out[r] = T( sum_k x[k] * code[nibble(r,k)] * absmax[(r*K+k)/blocksize] (+ bias[r]) )
+ * accumulated in f32.  x, out, bias are T[K], T[M], T[M]; bias may be NULL.
+ * With a bias the result is T( f32(T(sum)) + f32(bias[r]) ), i.e. exactly the
+ * reference's separate `out += bias` (torch_bnb_fp4/__init__.py:608-613) fused in.
+ * K must be even; K % 32 == 0 with a power-of-two blocksize >= 32 dividing K takes
+ * the fast path (the reference's own GEMV gate, torch_bnb_fp4/__init__.py:593).
+ * Replaces gemv_4bit_inference (csrc/gemv_fp4_optimized.cu:277-368; kernels :60-157
+ * half/bf16 and :159-259 float).  Always uses the CODE_PARAM table, as the
+ * reference does (its `datatype` tensor is ignored, csrc/gemv_fp4_optimized.cu:266,274).
+ */
+FP4_HIP_API int fp4_hip_gemv(const void *x, const uint8_t *packed, const float *absmax, const void *bias, void *out, int64_t M,
+                 int64_t K, int blocksize, int dtype, void *stream);
+
+/*
+ * Blockwise FP4 quantiser (the producer side; bitsandbytes' quantize_fp4 as called at
+ * torch_bnb_fp4/__init__.py:775 and inside Params4bit.cuda(), :861):
+ * per block of `blocksize` elements absmax = max|w|, code = nearest FP4 magnitude of
+ * w/absmax (midpoint thresholds, strict >), sign in bit 3, even element in the high
+ * nibble.  w is T[n] (w_dtype), packed uint8[(n+1)/2], absmax float[ceil(n/blocksize)].
+ * blocksize: power of two, 32..4096.
+ */
+FP4_HIP_API int fp4_hip_quantize_blockwise(const void *w, int w_dtype, uint8_t *packed, float *absmax, int64_t n, int blocksize,
+                               void *stream);
+
+/*
+ * Tuning hook for benchmarks/sweeps: selects a kernel geometry by name
+ * ("dequant", "gemv").  variant < 0 restores the built-in heuristic.
+ * Process-wide; not part of the reference surface.
+ */
+FP4_HIP_API int fp4_hip_set_variant(const char *kernel, int variant);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TORCH_BNB_FP4_HIP_H */

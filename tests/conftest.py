@@ -1,0 +1,36 @@
+import os
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG_ROOT = os.path.join(REPO, "torch-bnb-fp4_amd")
+for p in (REPO, PKG_ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    import numpy as np
+
+    path = os.path.join(REPO, "tests", "golden", "fp4_golden.npz")
+    return dict(np.load(path, allow_pickle=False))
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _native_built():
+    """Build the native artefacts once per session if they are missing (hipcc cross-compiles on CPU)."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("fp4_build", os.path.join(PKG_ROOT, "build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.build_all()
+    from oracle import c_oracle
+
+    c_oracle.build()

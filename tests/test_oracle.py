@@ -1,0 +1,188 @@
+"""CPU checks of the oracle itself: the two restatements against each other, against the
+committed golden vectors, and against everything the reference holds for this path (its table
+literals and its published acceptance statistic)."""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_oracle, fp4_oracle as o, torch_cpu
+
+
+def sha(a) -> np.ndarray:
+    return np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), np.uint8)
+
+
+def test_tables_match_reference_literals_via_c_compiler():
+    # oracle/fp4_oracle.c spells the literals exactly as csrc/dequant_fp4_optimized.cu:30-45,60-75
+    # does and lets gcc round them; the hex constants used everywhere else must agree bit for bit.
+    for name, tab in (("codebook", o.CODEBOOK_TABLE), ("tree", o.TREE_TABLE)):
+        assert (c_oracle.table(name).view(np.uint32) == tab.view(np.uint32)).all()
+    # the tree constants are k/12 rounded to f32 (bitsandbytes' quant_state.code) ...
+    k12 = (np.array([0, 0.0625, 8, 12, 4, 6, 2, 3], np.float64) / 12).astype(np.float32)
+    assert (o.TREE_TABLE[:8].view(np.uint32) == k12.view(np.uint32)).all()
+    # ... and CODE_PARAM differs from them only at magnitudes 1, 4, 6 (by 1, 12 and 2 ulp)
+    d = o.CODEBOOK_TABLE[:8].view(np.uint32).astype(np.int64) - o.TREE_TABLE[:8].view(np.uint32).astype(np.int64)
+    assert d.tolist() == [0, -1, 0, 0, -12, 0, 2, 0]
+    # nibble 8 is -0.0
+    assert o.CODEBOOK_TABLE.view(np.uint32)[8] == 0x80000000 and o.TREE_TABLE.view(np.uint32)[8] == 0x80000000
+
+
+def test_code_rounded_to_16bit_is_table_independent_and_c12_exact():
+    for rt in (o.round_to_bf16, o.round_to_f16):
+        assert (rt(o.CODEBOOK_TABLE) == rt(o.TREE_TABLE)).all()
+        assert (rt(o.C12_MAG) == o.C12_MAG).all()  # 12*code is exact in both 16-bit formats
+    assert np.allclose(o.C12_MAG / 12, o.TREE_TABLE[:8], rtol=1e-7)
+
+
+def test_nibble_order_high_first():
+    assert o.unpack_nibbles(np.array([0xAB, 0x01], np.uint8)).tolist() == [0xA, 0xB, 0x0, 0x1]
+
+
+def test_bf16_rounding_helpers_agree():
+    rng = np.random.default_rng(7)
+    x = (rng.standard_normal(200000) * np.exp(rng.uniform(-30, 30, 200000))).astype(np.float32)
+    assert (o.bf16_bits_to_f32(o.f32_to_bf16_bits(x)) == o.round_to_bf16(x)).all()
+    ties = np.array([1 + 2.0**-8, 1 + 3 * 2.0**-8, -(1 + 2.0**-8)], np.float32)
+    assert o.bf16_bits_to_f32(o.f32_to_bf16_bits(ties)).tolist() == [1.0, 1 + 2.0**-6, -1.0]
+
+
+@pytest.mark.parametrize("tb", ["codebook", "tree"])
+@pytest.mark.parametrize("dt,key", [("float32", "f32"), ("float16", "f16"), ("bfloat16", "bf16")])
+def test_both_oracles_match_golden_rounding_kat(golden, tb, dt, key):
+    packed, am = golden["kat3_packed"], golden["kat3_absmax"]
+    n = am.size * 64
+    want = golden[f"kat3_{tb}_{key}"]
+    with np.errstate(over="ignore"):
+        got_np = o.dequantize(packed, am, 64, n, dt, tb)
+    got_c = c_oracle.dequantize(packed, am, 64, n, dt, tb)
+    view = np.uint32 if dt == "float32" else np.uint16
+    assert (got_np.view(view) == want.view(view)).all()
+    assert (got_c.view(view) == want.view(view)).all()
+    if dt == "float16":  # the KAT really contains fp16 subnormal outputs
+        h = want.view(np.uint16)
+        assert ((h & 0x7C00) == 0).sum() > (h & 0x7FFF == 0).sum()
+
+
+def test_golden_exhaustive_bytes_and_absmax_index(golden):
+    for tb in ("codebook", "tree"):
+        want = golden[f"kat1_{tb}_f32"]
+        t = o.table(tb)
+        b = golden["kat1_packed"]
+        assert (want[0::2].view(np.uint32) == t[b >> 4].view(np.uint32)).all()
+        assert (want[1::2].view(np.uint32) == t[b & 15].view(np.uint32)).all()
+        got = c_oracle.dequantize(b, np.ones(8, np.float32), 64, 512, "float32", tb)
+        assert (got.view(np.uint32) == want.view(np.uint32)).all()
+    for bs in (64, 128, 32, 256):
+        am = golden[f"kat2_bs{bs}_absmax"]
+        want = golden[f"kat2_bs{bs}_f32"]
+        assert (want == np.repeat(am, bs)).all()  # nibble 3 = 1.0 -> output is the block's absmax
+        got = c_oracle.dequantize(golden[f"kat2_bs{bs}_packed"], am, bs, want.size, "float32")
+        assert (got == want).all()
+
+
+@pytest.mark.parametrize("tag", list("abcde"))
+def test_golden_tails(golden, tag):
+    packed, am, n = golden[f"kat4{tag}_packed"], golden[f"kat4{tag}_absmax"], int(golden[f"kat4{tag}_n"])
+    for impl in (o, c_oracle):
+        h = hashlib.sha256()
+        for dt in ("float32", "float16", "bfloat16"):
+            h.update(np.ascontiguousarray(impl.dequantize(packed, am, 64, n, dt)).tobytes())
+        assert (np.frombuffer(h.digest(), np.uint8) == golden[f"kat4{tag}_sha256"]).all()
+
+
+def test_config_c1_1024x1024_f32_plumbing(golden):
+    """BASELINE config 1: 1024x1024 Linear, blocksize 64, dequant to f32 on the CPU - three ways."""
+    w = np.random.default_rng(0).standard_normal(1024 * 1024).astype(np.float32)
+    assert (w[123456 : 123456 + 1024] == golden["c1_w_slice"]).all()
+    for quant in (o.quantize_fp4, c_oracle.quantize):
+        packed, am = quant(w, 64)
+        assert (sha(packed) == golden["c1_packed_sha256"]).all() and (sha(am) == golden["c1_absmax_sha256"]).all()
+    out_np = o.dequantize(packed, am, 64, w.size, "float32")
+    out_c = c_oracle.dequantize(packed, am, 64, w.size, "float32")
+    out_t = torch_cpu.dequantize(torch.from_numpy(packed), torch.from_numpy(am), 1024, 1024, 64, torch.float32).numpy().reshape(-1)
+    for out in (out_np, out_c, out_t):
+        assert (sha(out) == golden["c1_out_sha256"]).all()
+    assert (out_np[123456 : 123456 + 1024] == golden["c1_out_slice"]).all()
+    # FP4 with absmax scaling: relative error of the nearest-code rule is bounded by the widest gap
+    assert np.abs(out_np - w).max() <= np.repeat(am, 64).max() * (1 / 6 + 1e-6)
+
+
+def test_reference_absmax_rule_equals_flat_block_rule_for_multiples_of_16():
+    for bs in (16, 32, 64, 128, 4096):
+        n = bs * 5 + 17
+        assert (o.absmax_index(n, bs) == np.arange(n) // bs).all()
+    # ... and really is the one-lookup-per-8-bytes rule otherwise (csrc/dequant_fp4_optimized.cu:110)
+    assert o.absmax_index(32, 24).tolist() == [0] * 16 + [0] * 16  # bytes 0..7 -> 0/12, bytes 8..15 -> 8/12
+    assert o.absmax_index(64, 24).tolist()[32:48] == [1] * 16  # byte 16 / 12
+
+
+@pytest.mark.parametrize("tag", list("abc"))
+def test_gemv_oracles_agree_and_reference_emulation_is_close(golden, tag):
+    M, K = (int(v) for v in golden[f"gemv{tag}_shape"])
+    packed, am, x = golden[f"gemv{tag}_packed"], golden[f"gemv{tag}_absmax"], golden[f"gemv{tag}_x"]
+    exact = o.gemv_exact(x, packed, am, M, K, 64)
+    assert np.array_equal(exact, golden[f"gemv{tag}_exact"])
+    assert np.allclose(c_oracle.gemv_f64(x, packed, am, M, K, 64), exact, rtol=1e-12, atol=1e-15)
+    scale = np.abs(o.dequantize_f32(packed, am, 64, M * K).reshape(M, K).astype(np.float64)) @ np.abs(x.astype(np.float64))
+    for dt, eps in (("float32", 2.0**-20), ("float16", 2.0**-8), ("bfloat16", 2.0**-5)):
+        for fused in (False, True):
+            emu = o.gemv_reference_emulated(x, packed, am, M, K, 64, dt, fused=fused).astype(np.float64)
+            # the reference's T-precision accumulate stays within a few T-ulps of sum|x*w|
+            assert (np.abs(emu - exact) <= eps * scale + 1e-30).all(), (dt, fused)
+
+
+def test_quantiser_properties():
+    rng = np.random.default_rng(3)
+    w = rng.standard_normal(64 * 50 + 13).astype(np.float32)
+    w[64:128] = 0.0  # an all-zero block: absmax 0, every code 0
+    packed, am = o.quantize_fp4(w, 64)
+    p2, a2 = c_oracle.quantize(w, 64)
+    assert (packed == p2).all() and (am == a2).all()
+    assert am[1] == 0 and (packed[32:64] == 0).all()
+    deq = o.dequantize_f32(packed, am, 64, w.size, "tree")
+    # idempotence: re-quantising the dequantised weight reproduces scales and values (codes too,
+    # except that a small negative weight encodes as -0 = nibble 8, which re-quantises to nibble 0)
+    p3, a3 = o.quantize_fp4(deq, 64)
+    assert (a3 == am).all() and (o.dequantize_f32(p3, a3, 64, w.size, "tree") == deq).all()
+    n1, n3 = o.unpack_nibbles(packed)[: w.size], o.unpack_nibbles(p3)[: w.size]
+    assert ((n1 == n3) | ((n1 == 8) & (n3 == 0))).all()
+    # the element attaining absmax always encodes as +-1.0 (nibble 3 or 11)
+    nib = o.unpack_nibbles(packed)[: w.size]
+    blk0 = np.abs(w[:64]).argmax()
+    assert nib[blk0] in (3, 11)
+
+
+def _linear_stat(dtype: torch.dtype, shape, gen) -> float:
+    """mean |nn.Linear(x) - FP4Linear(x)| on a default-init 256x256 layer (sanity_check.py:130-171)."""
+    lin = torch.nn.Linear(256, 256)
+    w = lin.weight.detach().to(dtype)
+    b = lin.bias.detach().to(dtype)
+    # bitsandbytes casts the weight to fp16 before quantising (see the oracle header: unpinned)
+    packed, am = o.quantize_fp4(w.to(torch.float16).float().numpy().reshape(-1), 64)
+    wq = torch_cpu.dequantize(torch.from_numpy(packed), torch.from_numpy(am), 256, 256, 64, dtype)
+    x = torch.randn(*shape, generator=gen).to(dtype)
+    dense = torch.nn.functional.linear(x.float(), w.float(), b.float()).to(dtype)
+    fp4 = torch.nn.functional.linear(x.float(), wq.float(), b.float()).to(dtype)
+    return (dense.float() - fp4.float()).abs().mean().item()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+def test_reference_acceptance_statistic(dtype):
+    """The one number the reference publishes for this path: README.md:90-91 accepts 0.045-0.065 and
+    prints 0.049-0.057 for all nine cells (README.md:113-115,137-139,161-163)."""
+    torch.manual_seed(10)
+    gen = torch.Generator().manual_seed(10)
+    for shape in ((1, 1, 256), (1, 256), (1, 2048, 256)):
+        stat = _linear_stat(dtype, shape, gen)
+        assert 0.045 <= stat <= 0.065, (dtype, shape, stat)
+
+
+def test_dispatch_table():
+    # inputs -> branch of QuantData.forward (torch_bnb_fp4/__init__.py:560-618)
+    K, bs = 256, 64
+    cases = {(0, K): "empty", (1, K): "gemv", (1, 1, K): "gemv", (2, K): "qlinear", (1, 7, K): "qlinear",
+             (1, 1, 1, K): "qlinear", (1, 96): "qlinear"}
+    for shape, want in cases.items():
+        assert o.expected_dispatch(shape, shape[-1], bs) == want, shape

@@ -1,0 +1,89 @@
+"""In-tree build of the two native artefacts (gfx950 only):
+
+* ``torch_bnb_fp4/lib/libtorch_bnb_fp4_hip.so`` - the HIP kernels behind the C ABI
+  (``include/torch_bnb_fp4_hip.h``); no torch dependency.
+* ``torch_bnb_fp4_ext.so`` - the pybind/torch host layer (``csrc/torch_ext.cpp``), linked against
+  the first with an ``$ORIGIN`` rpath.
+
+Both are rebuilt only when a source is newer than the artefact.  hipcc cross-compiles without a
+GPU, so this runs in CI as well as on the GPU box.  Usage: ``python build.py [--force] [--no-ext]``.
+"""
+from __future__ import annotations
+
+import os
+import shlex
+import subprocess
+import sys
+import sysconfig
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+INCLUDE = os.path.join(REPO, "include")
+LIB_DIR = os.path.join(HERE, "torch_bnb_fp4", "lib")
+HIP_LIB = os.path.join(LIB_DIR, "libtorch_bnb_fp4_hip.so")
+EXT_LIB = os.path.join(HERE, "torch_bnb_fp4_ext.so")
+
+HIP_SOURCES = ["capi.hip", "dequant_fp4.hip", "gemv_fp4.hip", "quantize_fp4.hip"]
+HIP_HEADERS = ["fp4_common.h", os.path.join(INCLUDE, "torch_bnb_fp4_hip.h")]
+ARCH = "gfx950"
+
+
+def _hipcc() -> str:
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    cand = os.path.join(rocm, "bin", "hipcc")
+    return cand if os.path.exists(cand) else "hipcc"
+
+
+def _stale(target: str, deps) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _run(cmd) -> None:
+    print("+", " ".join(shlex.quote(c) for c in cmd), flush=True)
+    subprocess.check_call(cmd)
+
+
+def build_hip_lib(force: bool = False) -> str:
+    srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
+    deps = srcs + [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HIP_HEADERS] + [os.path.abspath(__file__)]
+    if force or _stale(HIP_LIB, deps):
+        os.makedirs(LIB_DIR, exist_ok=True)
+        _run([_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+              "-fvisibility=hidden", "-Wall", "-Wextra", f"-I{INCLUDE}", f"-I{CSRC}", *srcs, "-o", HIP_LIB])
+    return HIP_LIB
+
+
+def build_torch_ext(force: bool = False) -> str:
+    src = os.path.join(CSRC, "torch_ext.cpp")
+    deps = [src, os.path.join(INCLUDE, "torch_bnb_fp4_hip.h"), HIP_LIB, os.path.abspath(__file__)]
+    if not (force or _stale(EXT_LIB, deps)):
+        return EXT_LIB
+    import torch
+    from torch.utils import cpp_extension as ce
+
+    torch_lib = os.path.join(os.path.dirname(torch.__file__), "lib")
+    inc = [f"-I{p}" for p in ce.include_paths()] + [f"-I{sysconfig.get_paths()['include']}", f"-I{INCLUDE}",
+                                                     f"-I{os.environ.get('ROCM_PATH', '/opt/rocm')}/include"]
+    abi = int(torch._C._GLIBCXX_USE_CXX11_ABI)
+    _run([_hipcc(), "-O2", "-std=c++17", "-fPIC", "-shared", "-DTORCH_EXTENSION_NAME=torch_bnb_fp4_ext",
+          "-DTORCH_API_INCLUDE_EXTENSION_H", f"-D_GLIBCXX_USE_CXX11_ABI={abi}", "-DUSE_ROCM", "-Wno-unused-parameter",
+          *inc, src, "-o", EXT_LIB, f"-L{torch_lib}", "-lc10", "-lc10_hip", "-ltorch_cpu", "-ltorch", "-ltorch_hip",
+          "-ltorch_python", f"-L{LIB_DIR}", "-ltorch_bnb_fp4_hip", "-Wl,-rpath,$ORIGIN/torch_bnb_fp4/lib",
+          f"-Wl,-rpath,{torch_lib}"])
+    return EXT_LIB
+
+
+def build_all(force: bool = False, ext: bool = True):
+    out = [build_hip_lib(force)]
+    if ext:
+        out.append(build_torch_ext(force))
+    return out
+
+
+if __name__ == "__main__":
+    for path in build_all(force="--force" in sys.argv, ext="--no-ext" not in sys.argv):
+        print("built", os.path.relpath(path, REPO))

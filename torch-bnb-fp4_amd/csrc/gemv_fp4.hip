@@ -1,0 +1,446 @@
+// Fused batch-1 FP4 GEMV for gfx950 (MI355X):  out[r] = sum_k x[k] * code[nib(r,k)] * absmax[(r*K+k)/bs].
+//
+// Replaces gemv_4bit_inference_kernel / gemv_4bit_inference_kernel_float and their host
+// dispatcher (reference csrc/gemv_fp4_optimized.cu:60-368).  HBM-bound (0.5625 B of weight
+// stream per 2 flops), so no MFMA; what limits a naive wave64 kernel on this chip is VALU and
+// LDS issue, not memory: at 8 TB/s each CU must retire ~23 weights per clock, i.e. a budget of
+// ~5 VALU lane-ops per weight, and one LDS LUT read per weight would saturate the LDS pipe.
+//
+// Mapping (16-bit activations, the decode path):
+//  * one wave64 per output row (ROWS rows per wave, WAVES waves per workgroup); lane l owns
+//    16-byte chunks l, l+64, ... of the row = 32 weights each, always inside one quant block;
+//    all chunk loads of a trip are issued before any arithmetic.
+//  * the activation vector is staged once per workgroup in LDS, pre-permuted so that a lane's
+//    four ds_read_b128 are bank-conflict-free and line up with the decode below.
+//  * nibble -> value WITHOUT an LDS table: 12*|code| = {0, 1/16, 8, 12, 4, 6, 2, 3} is exact in
+//    fp16 and bf16, and its fp16 pattern fits one byte, so a v_perm_b32 with the 8-entry byte
+//    table as its 64-bit pool decodes four nibbles per instruction (bf16 needs a second byte
+//    plane).  Signs are OR-ed in from nibble bit 3.  Pairs feed v_dot2_f32_f16 / v_dot2_f32_bf16
+//    (f32 accumulate), ~2 VALU ops per weight in total.
+//  * absmax is factored out of the chunk: acc += absmax * sum_32(x * 12code); the final 1/12
+//    is applied once per row.  Accumulation is f32 throughout (the reference accumulates in
+//    half/bf16 per lane, csrc/gemv_fp4_optimized.cu:87,146-148), so results are closer to the
+//    exact x @ dequant(W)^T than the reference's, not bit-identical to it.
+//  * cross-lane sum: DPP row rotations (16 lanes) + ds_swizzle (32) + v_readlane (64); no LDS
+//    scratch, no barrier.
+// f32 activations use the CODE_PARAM f32 table from LDS (bit-faithful table, not the decode path).
+// A generic wave-per-row kernel covers every other shape (K % 32 != 0, odd block sizes, huge K).
+#include "fp4_common.h"
+
+namespace fp4 {
+
+namespace {
+
+// ---- byte tables for v_perm_b32: magnitude index 0..7 -> 12*|code| --------------------------
+// fp16 patterns 0x0000 0x2C00 0x4800 0x4A00 0x4400 0x4600 0x4000 0x4200 (low byte always 0)
+constexpr uint32_t kF16HiLo = 0x4A482C00u, kF16HiHi = 0x42404644u;
+// bf16 patterns 0x0000 0x3D80 0x4100 0x4140 0x4080 0x40C0 0x4000 0x4040
+constexpr uint32_t kBf16HiLo = 0x41413D00u, kBf16HiHi = 0x40404040u;
+constexpr uint32_t kBf16LoLo = 0x40008000u, kBf16LoHi = 0x4000C080u;
+
+__device__ __forceinline__ uint32_t perm(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
+
+// One packed dword = 8 weights e0..e7 (byte b holds e_2b in its high nibble, e_2b+1 in its low
+// nibble).  Produces four 16-bit pairs of 12*code: P0=(e0,e2) P1=(e4,e6) P2=(e1,e3) P3=(e5,e7).
+template <int DT>
+__device__ __forceinline__ void decode8(uint32_t q, uint32_t (&P)[4]) {
+    const uint32_t lo_sel = q & 0x07070707u;         // magnitudes of e1,e3,e5,e7
+    const uint32_t hi_sel = (q >> 4) & 0x07070707u;  // magnitudes of e0,e2,e4,e6
+    const uint32_t lo_sgn = (q & 0x08080808u) << 4;  // sign -> bit 7 of each byte
+    const uint32_t hi_sgn = q & 0x80808080u;
+    if constexpr (DT == FP4_DTYPE_F16) {
+        const uint32_t mhi = perm(kF16HiHi, kF16HiLo, hi_sel) | hi_sgn;
+        const uint32_t mlo = perm(kF16HiHi, kF16HiLo, lo_sel) | lo_sgn;
+        P[0] = perm(0u, mhi, 0x010C000Cu);
+        P[1] = perm(0u, mhi, 0x030C020Cu);
+        P[2] = perm(0u, mlo, 0x010C000Cu);
+        P[3] = perm(0u, mlo, 0x030C020Cu);
+    } else {
+        const uint32_t hH = perm(kBf16HiHi, kBf16HiLo, hi_sel) | hi_sgn;
+        const uint32_t hL = perm(kBf16LoHi, kBf16LoLo, hi_sel);
+        const uint32_t lH = perm(kBf16HiHi, kBf16HiLo, lo_sel) | lo_sgn;
+        const uint32_t lL = perm(kBf16LoHi, kBf16LoLo, lo_sel);
+        P[0] = perm(hH, hL, 0x05010400u);
+        P[1] = perm(hH, hL, 0x07030602u);
+        P[2] = perm(lH, lL, 0x05010400u);
+        P[3] = perm(lH, lL, 0x07030602u);
+    }
+}
+
+template <int DT>
+__device__ __forceinline__ float dot2(uint32_t a, uint32_t b, float c) {
+    if constexpr (DT == FP4_DTYPE_F16)
+        return __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, a), __builtin_bit_cast(f16x2, b), c, false);
+    else
+        return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, a), __builtin_bit_cast(bf16x2, b), c, false);
+}
+
+// ---- wave64 all-lanes sum without LDS storage -------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+    const int moved = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false);
+    return v + __builtin_bit_cast(float, moved);
+}
+__device__ __forceinline__ float wave_sum(float v) {
+    v = dpp_add<0x128>(v);  // row_ror:8
+    v = dpp_add<0x124>(v);  // row_ror:4
+    v = dpp_add<0x122>(v);  // row_ror:2
+    v = dpp_add<0x121>(v);  // row_ror:1   -> every lane holds its 16-lane row sum
+    v += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));  // lane ^ 16
+    const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+    const float b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+    return a + b;
+}
+
+template <int DT>
+__device__ __forceinline__ void store_row(uint16_t *out, const uint16_t *bias, int row, float sum) {
+    uint16_t t = from_f32<DT>(sum);
+    // reference: out = T(gemv); out += bias  (torch_bnb_fp4/__init__.py:608-613) -> two roundings
+    if (bias) t = from_f32<DT>(to_f32<DT>(t) + to_f32<DT>(bias[row]));
+    out[row] = t;
+}
+
+// ---- 16-bit activations: the decode path -----------------------------------------------------
+// LDS image of x: group g (8 values) of chunk c sits at 16-byte slot [g*C + c], holding the
+// dwords (x0,x2) (x4,x6) (x1,x3) (x5,x7) that pair with decode8's P0..P3.
+template <int ROWS, int UNROLL>
+struct WTrip {  // one trip of a wave: UNROLL chunks x ROWS rows of packed weights + their scales
+    u32x4 wq[UNROLL][ROWS];
+    float am[UNROLL][ROWS];
+};
+
+template <int ROWS, int UNROLL>
+__device__ __forceinline__ void issue_trip(WTrip<ROWS, UNROLL> &t, const u32x4 *__restrict__ Wv,
+                                           const float *__restrict__ absmax, const int (&rows)[ROWS], int c0, int C,
+                                           int bs_shift) {
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+        const int c = c0 + 64 * u;
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const int64_t chunk = int64_t(rows[r]) * C + c;
+            if (c < C) {
+                t.wq[u][r] = __builtin_nontemporal_load(Wv + chunk);
+                t.am[u][r] = absmax[(chunk << 5) >> bs_shift];
+            } else {
+                t.wq[u][r] = u32x4{0u, 0u, 0u, 0u};
+                t.am[u][r] = 0.0f;
+            }
+        }
+    }
+}
+
+template <int DT, int ROWS, int UNROLL>
+__device__ __forceinline__ void consume_trip(const WTrip<ROWS, UNROLL> &t, const u32x4 *s_x4, int c0, int C,
+                                             float (&acc)[ROWS]) {
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+        const int c = c0 + 64 * u;
+        if (c < C) {
+            u32x4 xd[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) xd[g] = s_x4[g * C + c];
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) {
+                float s[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    uint32_t P[4];
+                    decode8<DT>(t.wq[u][r][g], P);
+                    s[g] = dot2<DT>(P[0], xd[g].x, s[g]);
+                    s[g] = dot2<DT>(P[1], xd[g].y, s[g]);
+                    s[g] = dot2<DT>(P[2], xd[g].z, s[g]);
+                    s[g] = dot2<DT>(P[3], xd[g].w, s[g]);
+                }
+                acc[r] = __builtin_fmaf((s[0] + s[1]) + (s[2] + s[3]), t.am[u][r], acc[r]);
+            }
+        }
+    }
+}
+
+template <int DT, int ROWS, int WAVES, int UNROLL>
+__global__ __launch_bounds__(WAVES * 64) void gemv16_kernel(const uint16_t *__restrict__ x,
+                                                            const uint8_t *__restrict__ W,
+                                                            const float *__restrict__ absmax,
+                                                            const uint16_t *__restrict__ bias,
+                                                            uint16_t *__restrict__ out, int M, int K, int bs_shift) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_x[];
+    u32x4 *s_x4 = reinterpret_cast<u32x4 *>(s_x);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int C = K >> 5;  // 32-weight chunks per row
+    constexpr int kStride = 64 * UNROLL;
+    const int trips = (C + kStride - 1) / kStride;
+
+    const int row0 = (blockIdx.x * WAVES + wave) * ROWS;
+    int rows[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) rows[r] = (row0 + r < M) ? row0 + r : M - 1;  // clamped rows are computed, not stored
+    const u32x4 *Wv = reinterpret_cast<const u32x4 *>(W);
+
+    // the weight stream of the first trip goes out before anything else: it is the HBM-latency-bound part
+    WTrip<ROWS, UNROLL> ta, tb;
+    issue_trip<ROWS, UNROLL>(ta, Wv, absmax, rows, lane, C, bs_shift);
+
+    for (int p = tid; p < 4 * C; p += WAVES * 64) {
+        const u32x4 w = reinterpret_cast<const u32x4 *>(x)[p];
+        u32x4 d;
+        d.x = perm(w.y, w.x, 0x05040100u);  // (x0,x2)
+        d.y = perm(w.w, w.z, 0x05040100u);  // (x4,x6)
+        d.z = perm(w.y, w.x, 0x07060302u);  // (x1,x3)
+        d.w = perm(w.w, w.z, 0x07060302u);  // (x5,x7)
+        s_x4[(p & 3) * C + (p >> 2)] = d;
+    }
+    __syncthreads();
+
+    float acc[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) acc[r] = 0.0f;
+
+    // ping-pong the two register sets so the next trip's loads fly while this one is consumed
+    for (int t = 0;;) {
+        if (t + 1 < trips) issue_trip<ROWS, UNROLL>(tb, Wv, absmax, rows, lane + (t + 1) * kStride, C, bs_shift);
+        consume_trip<DT, ROWS, UNROLL>(ta, s_x4, lane + t * kStride, C, acc);
+        if (++t >= trips) break;
+        if (t + 1 < trips) issue_trip<ROWS, UNROLL>(ta, Wv, absmax, rows, lane + (t + 1) * kStride, C, bs_shift);
+        consume_trip<DT, ROWS, UNROLL>(tb, s_x4, lane + t * kStride, C, acc);
+        if (++t >= trips) break;
+    }
+
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        const float total = wave_sum(acc[r]) * (1.0f / 12.0f);
+        if (lane == 0 && row0 + r < M) store_row<DT>(out, bias, row0 + r, total);
+    }
+}
+
+// ---- f32 activations: CODE_PARAM f32 table in LDS -----------------------------------------------
+// LDS image of x: 4-float group g (0..7) of chunk c at 16-byte slot [g*C + c].
+template <int ROWS, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void gemv32_kernel(const float *__restrict__ x, const uint8_t *__restrict__ W,
+                                                            const float *__restrict__ absmax,
+                                                            const float *__restrict__ bias, float *__restrict__ out, int M,
+                                                            int K, int bs_shift) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_raw[];
+    f32x4 *s_x4 = reinterpret_cast<f32x4 *>(s_raw);
+    __shared__ float s_lut[16];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int C = K >> 5;
+
+    if (tid < 16) s_lut[tid] = lut_entry(FP4_TABLE_CODEBOOK, tid);
+    for (int p = tid; p < 8 * C; p += WAVES * 64) s_x4[(p & 7) * C + (p >> 3)] = reinterpret_cast<const f32x4 *>(x)[p];
+    __syncthreads();
+
+    const int row0 = (blockIdx.x * WAVES + wave) * ROWS;
+    if (row0 >= M) return;
+    int rows[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) rows[r] = (row0 + r < M) ? row0 + r : M - 1;
+
+    const u32x4 *Wv = reinterpret_cast<const u32x4 *>(W);
+    float acc[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) acc[r] = 0.0f;
+
+    for (int c = lane; c < C; c += 64) {
+        u32x4 wq[ROWS];
+        float am[ROWS];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const int64_t chunk = int64_t(rows[r]) * C + c;
+            wq[r] = __builtin_nontemporal_load(Wv + chunk);
+            am[r] = absmax[(chunk << 5) >> bs_shift];
+        }
+        float s[ROWS];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) s[r] = 0.0f;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const f32x4 xv = s_x4[g * C + c];  // weights 4g..4g+3 of the chunk = bytes 2g, 2g+1
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) {
+                const uint32_t h = (wq[r][g >> 1] >> (16 * (g & 1))) & 0xFFFFu;  // two bytes
+                s[r] = __builtin_fmaf(s_lut[(h >> 4) & 15u], xv.x, s[r]);
+                s[r] = __builtin_fmaf(s_lut[h & 15u], xv.y, s[r]);
+                s[r] = __builtin_fmaf(s_lut[(h >> 12) & 15u], xv.z, s[r]);
+                s[r] = __builtin_fmaf(s_lut[(h >> 8) & 15u], xv.w, s[r]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) acc[r] = __builtin_fmaf(s[r], am[r], acc[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        const float total = wave_sum(acc[r]);
+        if (lane == 0 && row0 + r < M) out[row0 + r] = bias ? total + bias[row0 + r] : total;
+    }
+}
+
+// ---- generic: any even K, any even blocksize, no alignment assumptions ---------------------------
+template <int DT>
+__global__ __launch_bounds__(256) void gemv_generic_kernel(const void *__restrict__ xv, const uint8_t *__restrict__ W,
+                                                           const float *__restrict__ absmax, const void *__restrict__ biasv,
+                                                           void *__restrict__ outv, int M, int64_t K, int blocksize,
+                                                           CodeTable tbl) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int64_t e_row = int64_t(row) * K;
+    float acc = 0.0f;
+    for (int64_t b = lane; b < K / 2; b += 64) {
+        const int64_t e = e_row + 2 * b;
+        const uint32_t q = W[e >> 1];
+        const float am = absmax[e / blocksize];
+        float x0, x1;
+        if constexpr (DT == FP4_DTYPE_F32) {
+            x0 = reinterpret_cast<const float *>(xv)[2 * b];
+            x1 = reinterpret_cast<const float *>(xv)[2 * b + 1];
+        } else {
+            x0 = to_f32<DT>(reinterpret_cast<const uint16_t *>(xv)[2 * b]);
+            x1 = to_f32<DT>(reinterpret_cast<const uint16_t *>(xv)[2 * b + 1]);
+        }
+        acc = __builtin_fmaf(__builtin_bit_cast(float, tbl.bits[q >> 4]) * am, x0, acc);
+        acc = __builtin_fmaf(__builtin_bit_cast(float, tbl.bits[q & 15u]) * am, x1, acc);
+    }
+    const float total = wave_sum(acc);
+    if (lane == 0) {
+        if constexpr (DT == FP4_DTYPE_F32) {
+            const float *bias = reinterpret_cast<const float *>(biasv);
+            reinterpret_cast<float *>(outv)[row] = bias ? total + bias[row] : total;
+        } else {
+            store_row<DT>(reinterpret_cast<uint16_t *>(outv), reinterpret_cast<const uint16_t *>(biasv), row, total);
+        }
+    }
+}
+
+int g_gemv_variant = -1;  // ROWS | WAVES << 8 | UNROLL << 16, or -1 = heuristic
+
+constexpr int kMaxLdsBytes = 160 * 1024 - 256;
+
+template <typename Kern>
+int ensure_lds(Kern kern, size_t lds_bytes) {
+    if (lds_bytes <= 64 * 1024) return FP4_OK;
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds_bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("fp4_hip_gemv: cannot reserve %zu bytes of LDS", lds_bytes);
+        return FP4_ERR_UNSUPPORTED;
+    }
+    return FP4_OK;
+}
+
+template <int DT, int ROWS, int WAVES, int UNROLL>
+int launch16(const void *x, const uint8_t *W, const float *absmax, const void *bias, void *out, int M, int K, int bs_shift,
+             hipStream_t stream) {
+    auto kern = gemv16_kernel<DT, ROWS, WAVES, UNROLL>;
+    const size_t lds = size_t(K) * 2;
+    if (int rc = ensure_lds(kern, lds)) return rc;
+    const int rows_per_block = ROWS * WAVES;
+    const unsigned blocks = (unsigned)((M + rows_per_block - 1) / rows_per_block);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(WAVES * 64), lds, stream, reinterpret_cast<const uint16_t *>(x), W, absmax,
+                       reinterpret_cast<const uint16_t *>(bias), reinterpret_cast<uint16_t *>(out), M, K, bs_shift);
+    return FP4_OK;
+}
+
+template <int DT>
+int dispatch16(int variant, const void *x, const uint8_t *W, const float *absmax, const void *bias, void *out, int M, int K,
+               int bs_shift, hipStream_t stream) {
+    switch (variant) {
+#define FP4_V(R, Wv, U)                  \
+    case (R | (Wv << 8) | (U << 16)):    \
+        return launch16<DT, R, Wv, U>(x, W, absmax, bias, out, M, K, bs_shift, stream);
+        FP4_V(1, 4, 1) FP4_V(1, 4, 2) FP4_V(2, 4, 1) FP4_V(2, 4, 2) FP4_V(4, 4, 1) FP4_V(4, 4, 2)
+        FP4_V(1, 8, 1) FP4_V(1, 8, 2) FP4_V(2, 8, 1) FP4_V(2, 8, 2) FP4_V(4, 8, 1) FP4_V(4, 8, 2)
+        FP4_V(1, 16, 2) FP4_V(2, 16, 2)
+#undef FP4_V
+        default:
+            set_error("fp4_hip_gemv: unknown kernel variant 0x%x", variant);
+            return FP4_ERR_INVALID_ARGUMENT;
+    }
+}
+
+int default_variant16(int M, int K) {
+    (void)K;
+    // one wave per row, 4 waves per workgroup; fold rows into a wave only when M alone
+    // already gives every CU several workgroups
+    int rows = 1;
+    if (M >= 8192) rows = 2;
+    return rows | (4 << 8) | (2 << 16);
+}
+
+template <int DT>
+int run_generic(const void *x, const uint8_t *W, const float *absmax, const void *bias, void *out, int64_t M, int64_t K,
+                int blocksize, hipStream_t stream) {
+    const CodeTable tbl = make_table(FP4_TABLE_CODEBOOK);
+    hipLaunchKernelGGL((gemv_generic_kernel<DT>), dim3((unsigned)((M + 3) / 4)), dim3(256), 0, stream, x, W, absmax, bias,
+                       out, (int)M, K, blocksize, tbl);
+    return FP4_OK;
+}
+
+}  // namespace
+
+void set_gemv_variant(int v) { g_gemv_variant = v; }
+
+}  // namespace fp4
+
+extern "C" int fp4_hip_gemv(const void *x, const uint8_t *packed, const float *absmax, const void *bias, void *out,
+                            int64_t M, int64_t K, int blocksize, int dtype, void *stream) {
+    using namespace fp4;
+    if (M < 0 || K < 0 || (K & 1) || blocksize < 2 || (blocksize & 1)) {
+        set_error("fp4_hip_gemv: M=%lld K=%lld blocksize=%d (need M,K >= 0, even K, even blocksize >= 2)", (long long)M,
+                  (long long)K, blocksize);
+        return FP4_ERR_INVALID_ARGUMENT;
+    }
+    if (dtype != FP4_DTYPE_F16 && dtype != FP4_DTYPE_BF16 && dtype != FP4_DTYPE_F32) {
+        // reference: std::runtime_error("Unsupported datatype") (csrc/gemv_fp4_optimized.cu:362-363)
+        set_error("fp4_hip_gemv: unsupported dtype %d", dtype);
+        return FP4_ERR_UNSUPPORTED;
+    }
+    if (M == 0) return FP4_OK;
+    if (!out || (K > 0 && (!x || !packed || !absmax))) {
+        set_error("fp4_hip_gemv: null pointer");
+        return FP4_ERR_INVALID_ARGUMENT;
+    }
+    if (M > (int64_t(1) << 30) || K > (int64_t(1) << 30)) {
+        set_error("fp4_hip_gemv: M=%lld K=%lld too large", (long long)M, (long long)K);
+        return FP4_ERR_UNSUPPORTED;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int bs_shift = ilog2_exact(blocksize);
+    const uintptr_t align = reinterpret_cast<uintptr_t>(packed) | reinterpret_cast<uintptr_t>(x);
+    const size_t esz = dtype == FP4_DTYPE_F32 ? 4 : 2;
+    const bool fast = K > 0 && (K % 32) == 0 && bs_shift >= 5 && (K % blocksize) == 0 && (align & 15u) == 0 &&
+                      size_t(K) * esz <= size_t(kMaxLdsBytes);
+    int rc = FP4_OK;
+    if (fast && dtype != FP4_DTYPE_F32) {
+        const int variant = g_gemv_variant >= 0 ? g_gemv_variant : default_variant16((int)M, (int)K);
+        rc = dtype == FP4_DTYPE_F16
+                 ? dispatch16<FP4_DTYPE_F16>(variant, x, packed, absmax, bias, out, (int)M, (int)K, bs_shift, s)
+                 : dispatch16<FP4_DTYPE_BF16>(variant, x, packed, absmax, bias, out, (int)M, (int)K, bs_shift, s);
+    } else if (fast) {
+        auto kern = gemv32_kernel<1, 4>;
+        const size_t lds = size_t(K) * 4;
+        rc = ensure_lds(kern, lds);
+        if (rc == FP4_OK)
+            hipLaunchKernelGGL(kern, dim3((unsigned)((M + 3) / 4)), dim3(256), lds, s, reinterpret_cast<const float *>(x),
+                               packed, absmax, reinterpret_cast<const float *>(bias), reinterpret_cast<float *>(out), (int)M,
+                               (int)K, bs_shift);
+    } else {
+        switch (dtype) {
+            case FP4_DTYPE_F16:
+                rc = run_generic<FP4_DTYPE_F16>(x, packed, absmax, bias, out, M, K, blocksize, s);
+                break;
+            case FP4_DTYPE_BF16:
+                rc = run_generic<FP4_DTYPE_BF16>(x, packed, absmax, bias, out, M, K, blocksize, s);
+                break;
+            default:
+                rc = run_generic<FP4_DTYPE_F32>(x, packed, absmax, bias, out, M, K, blocksize, s);
+                break;
+        }
+    }
+    if (rc != FP4_OK) return rc;
+    return check_launch("fp4_hip_gemv");
+}

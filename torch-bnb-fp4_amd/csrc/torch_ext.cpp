@@ -1,0 +1,230 @@
+// torch_bnb_fp4_ext -- the PyTorch-ROCm host layer above the C ABI (include/torch_bnb_fp4_hip.h).
+//
+// Re-exports the operator surface of the reference's pybind module (reference
+// csrc/torch_fp4.cpp:125-139): ScalarType + dequantize_fp4, dequantize_fp4_codebook, gemv_fp4,
+// qlinear, qlinear_bias, qlinear_codebook, qlinear_codebook_bias, with the same positional
+// signatures, argument meaning and error behaviour (RuntimeError on a non-GPU / non-contiguous
+// tensor, TypeError on a bad enum).  PyTorch is plumbing only: it owns device memory, the current
+// stream and the batch>1 GEMM (at::linear -> hipBLASLt/rocBLAS); every FP4 kernel is behind the
+// C ABI.  Differences from the reference, all deliberate:
+//   * launches go to the CURRENT torch stream under a device guard (the reference uses the legacy
+//     default stream and no guard, csrc/dequant_fp4_optimized.cu:176, csrc/gemv_fp4_optimized.cu:266);
+//   * launch / dtype failures raise instead of printf (csrc/dequant_fp4_optimized.cu:48-53,201-203);
+//   * qlinear_codebook* dequantise all M*N elements (the reference passes the BYTE count,
+//     csrc/torch_fp4.cpp:90,101, leaving half of the weight uninitialised).
+// Extra exports (not in the reference): gemv_fp4_bias, quantize_fp4, set_kernel_variant, code_table.
+#include <c10/core/DeviceGuard.h>
+#include <c10/hip/HIPStream.h>
+#include <torch/extension.h>
+
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "torch_bnb_fp4_hip.h"
+
+namespace {
+
+enum class ScalarTypeEnum { float16 = FP4_DTYPE_F16, float32 = FP4_DTYPE_F32, bfloat16 = FP4_DTYPE_BF16 };
+
+torch::ScalarType to_torch(ScalarTypeEnum t) {
+    switch (t) {
+        case ScalarTypeEnum::float16:
+            return torch::kFloat16;
+        case ScalarTypeEnum::float32:
+            return torch::kFloat32;
+        case ScalarTypeEnum::bfloat16:
+            return torch::kBFloat16;
+    }
+    throw py::type_error("Unsupported scalar type");
+}
+
+int to_fp4_dtype(torch::ScalarType t, const char *what) {
+    switch (t) {
+        case torch::kFloat16:
+            return FP4_DTYPE_F16;
+        case torch::kFloat32:
+            return FP4_DTYPE_F32;
+        case torch::kBFloat16:
+            return FP4_DTYPE_BF16;
+        default:
+            TORCH_CHECK(false, what, ": unsupported dtype ", t, " (need float16, bfloat16 or float32)");
+    }
+}
+
+void check_gpu_contiguous(const torch::Tensor &t, const char *name) {
+    // reference: CHECK_CUDA / CHECK_CONTIGUOUS (csrc/torch_fp4.cpp:19-20)
+    TORCH_CHECK(t.is_cuda(), name, " must be a CUDA tensor");
+    TORCH_CHECK(t.is_contiguous(), name, " must be contiguous");
+}
+
+void check_status(int rc) {
+    if (rc == FP4_OK) return;
+    const std::string msg = fp4_hip_last_error();
+    if (rc == FP4_ERR_UNSUPPORTED && msg.find("dtype") != std::string::npos) throw std::runtime_error("Unsupported datatype: " + msg);
+    TORCH_CHECK(false, msg);
+}
+
+void *current_stream(const torch::Tensor &t) { return c10::hip::getCurrentHIPStream(t.device().index()).stream(); }
+
+// dequant of the first n elements of `out` (out is [M,N], n <= M*N)
+void dequant_into(const torch::Tensor &A, const torch::Tensor &absmax, torch::Tensor &out, int64_t blocksize, int64_t n,
+                  int table) {
+    // reference: TORCH_CHECKs of csrc/dequant_fp4_optimized.cu:183-187,210-213
+    TORCH_CHECK(A.dtype() == torch::kUInt8, "A must be uint8");
+    TORCH_CHECK(absmax.dtype() == torch::kFloat32, "absmax must be float32");
+    TORCH_CHECK(A.is_cuda(), "A must be cuda");
+    TORCH_CHECK(absmax.is_cuda(), "absmax must be cuda");
+    TORCH_CHECK(out.is_cuda(), "out must be cuda");
+    TORCH_CHECK(absmax.device() == A.device() && out.device() == A.device(), "A, absmax and out must be on one device");
+    TORCH_CHECK(n >= 0 && n <= out.numel(), "n = ", n, " does not fit the [M, N] output (", out.numel(), " elements)");
+    TORCH_CHECK(blocksize >= 2 && blocksize % 2 == 0, "blocksize must be even and >= 2");
+    TORCH_CHECK(A.numel() >= (n + 1) / 2, "packed tensor holds ", A.numel(), " bytes, ", (n + 1) / 2, " needed");
+    TORCH_CHECK(absmax.numel() >= (n + blocksize - 1) / blocksize, "absmax holds ", absmax.numel(), " scales, ",
+                (n + blocksize - 1) / blocksize, " needed");
+    const int dt = to_fp4_dtype(out.scalar_type(), "dequantize");
+    c10::DeviceGuard guard(A.device());
+    check_status(fp4_hip_dequantize_blockwise(A.data_ptr<uint8_t>(), absmax.data_ptr<float>(), out.data_ptr(), (int)blocksize,
+                                              n, dt, table, current_stream(A)));
+}
+
+torch::Tensor dequantize_fp4(torch::Tensor A, torch::Tensor absmax, int blocksize, int M, int N, ScalarTypeEnum o_type) {
+    check_gpu_contiguous(A, "A");
+    check_gpu_contiguous(absmax, "absmax");
+    torch::Tensor out = torch::empty({M, N}, torch::TensorOptions().dtype(to_torch(o_type)).device(A.device()));
+    dequant_into(A, absmax, out, blocksize, int64_t(M) * N, FP4_TABLE_TREE);
+    return out;
+}
+
+torch::Tensor dequantize_fp4_codebook(torch::Tensor A, torch::Tensor absmax, torch::Tensor codebook, int M, int N,
+                                      int blocksize, int64_t n, ScalarTypeEnum dtype) {
+    check_gpu_contiguous(A, "A");
+    check_gpu_contiguous(absmax, "absmax");
+    check_gpu_contiguous(codebook, "codebook");  // checked but unused, like the reference (its kernels use CODE_PARAM)
+    torch::Tensor out = torch::empty({M, N}, torch::TensorOptions().dtype(to_torch(dtype)).device(A.device()));
+    dequant_into(A, absmax, out, blocksize, n, FP4_TABLE_CODEBOOK);
+    return out;
+}
+
+torch::Tensor qlinear_impl(const torch::Tensor &A_in, const torch::Tensor &A, const torch::Tensor &absmax, int M, int N,
+                           int blocksize, int table, const c10::optional<torch::Tensor> &bias) {
+    check_gpu_contiguous(A, "A");
+    check_gpu_contiguous(absmax, "absmax");
+    torch::Tensor weight = torch::empty({M, N}, A_in.options());
+    dequant_into(A, absmax, weight, blocksize, int64_t(M) * N, table);
+    return bias.has_value() ? at::linear(A_in, weight, *bias) : at::linear(A_in, weight);
+}
+
+torch::Tensor qlinear(torch::Tensor A_in, torch::Tensor A, torch::Tensor absmax, int M, int N, int blocksize) {
+    return qlinear_impl(A_in, A, absmax, M, N, blocksize, FP4_TABLE_TREE, c10::nullopt);
+}
+torch::Tensor qlinear_bias(torch::Tensor A_in, torch::Tensor A, torch::Tensor absmax, int M, int N, int blocksize,
+                           torch::Tensor bias) {
+    return qlinear_impl(A_in, A, absmax, M, N, blocksize, FP4_TABLE_TREE, bias);
+}
+torch::Tensor qlinear_codebook(torch::Tensor A_in, torch::Tensor A, torch::Tensor absmax, torch::Tensor codebook, int M, int N,
+                               int blocksize) {
+    (void)codebook;
+    return qlinear_impl(A_in, A, absmax, M, N, blocksize, FP4_TABLE_CODEBOOK, c10::nullopt);
+}
+torch::Tensor qlinear_codebook_bias(torch::Tensor A_in, torch::Tensor A, torch::Tensor absmax, torch::Tensor codebook, int M,
+                                    int N, int blocksize, torch::Tensor bias) {
+    (void)codebook;
+    return qlinear_impl(A_in, A, absmax, M, N, blocksize, FP4_TABLE_CODEBOOK, bias);
+}
+
+torch::Tensor gemv_impl(const torch::Tensor &A, const torch::Tensor &B, const torch::Tensor &absmax,
+                        const torch::Tensor &datatype, int blocksize, ScalarTypeEnum dtype, const std::vector<uint32_t> &Bshape,
+                        const c10::optional<torch::Tensor> &bias) {
+    check_gpu_contiguous(A, "A");
+    check_gpu_contiguous(B, "B");
+    check_gpu_contiguous(absmax, "absmax");
+    check_gpu_contiguous(datatype, "datatype");
+    TORCH_CHECK(Bshape.size() == 2, "Bshape must be the [out_features, in_features] of the quantised weight");
+    const int64_t m = Bshape[0], k = Bshape[1];
+    const torch::ScalarType st = to_torch(dtype);
+    // reference: per-dtype TORCH_CHECKs of csrc/gemv_fp4_optimized.cu:303-305,323-325,343-345
+    TORCH_CHECK(A.scalar_type() == st, "gemv_fp4: dtype argument (", st, ") must equal the activation dtype (", A.scalar_type(), ")");
+    TORCH_CHECK(absmax.scalar_type() == torch::kFloat32, "Only fp32 absmax is supported");
+    TORCH_CHECK(datatype.scalar_type() == torch::kFloat32, "Only fp32 code is supported");
+    TORCH_CHECK(B.dtype() == torch::kUInt8, "B must be uint8");
+    TORCH_CHECK(A.dim() == 2 || A.dim() == 3, "gemv_fp4: activation must be [1, K] or [1, 1, K]");
+    TORCH_CHECK(A.numel() == k && A.size(-1) == k, "gemv_fp4 is batch-1 only: activation has ", A.numel(),
+                " elements, in_features is ", k);
+    TORCH_CHECK(B.numel() * 2 >= m * k, "B holds ", B.numel(), " bytes, ", m * k / 2, " needed");
+    TORCH_CHECK(absmax.numel() * int64_t(blocksize) >= m * k, "absmax too small for a ", m, "x", k, " weight");
+    TORCH_CHECK(B.device() == A.device() && absmax.device() == A.device(), "all tensors must be on one device");
+    // reference output shape: [A.size(0), m] or [A.size(0), A.size(1), m] (csrc/gemv_fp4_optimized.cu:296-299)
+    torch::Tensor out = A.dim() == 3 ? torch::empty({A.size(0), A.size(1), m}, A.options()) : torch::empty({A.size(0), m}, A.options());
+    const void *bias_ptr = nullptr;
+    torch::Tensor bias_c;
+    if (bias.has_value()) {
+        TORCH_CHECK(bias->is_cuda() && bias->numel() == m && bias->scalar_type() == st, "bias must be a [", m, "] tensor of ", st);
+        bias_c = bias->contiguous();
+        bias_ptr = bias_c.data_ptr();
+    }
+    c10::DeviceGuard guard(A.device());
+    check_status(fp4_hip_gemv(A.data_ptr(), B.data_ptr<uint8_t>(), absmax.data_ptr<float>(), bias_ptr, out.data_ptr(), m, k,
+                              blocksize, (int)dtype, current_stream(A)));
+    return out;
+}
+
+torch::Tensor gemv_fp4(torch::Tensor A, torch::Tensor B, torch::Tensor absmax, torch::Tensor datatype, int blocksize,
+                       ScalarTypeEnum dtype, std::vector<uint32_t> Bshape) {
+    return gemv_impl(A, B, absmax, datatype, blocksize, dtype, Bshape, c10::nullopt);
+}
+torch::Tensor gemv_fp4_bias(torch::Tensor A, torch::Tensor B, torch::Tensor absmax, torch::Tensor datatype, int blocksize,
+                            ScalarTypeEnum dtype, std::vector<uint32_t> Bshape, torch::Tensor bias) {
+    return gemv_impl(A, B, absmax, datatype, blocksize, dtype, Bshape, bias);
+}
+
+// bitsandbytes-format FP4 quantisation of a float tensor: returns (packed uint8[ceil(n/2), 1], absmax float32[ceil(n/bs)])
+std::tuple<torch::Tensor, torch::Tensor> quantize_fp4(torch::Tensor W, int blocksize) {
+    check_gpu_contiguous(W, "W");
+    const int dt = to_fp4_dtype(W.scalar_type(), "quantize_fp4");
+    const int64_t n = W.numel();
+    TORCH_CHECK(blocksize > 0, "blocksize must be positive");
+    torch::Tensor packed = torch::empty({(n + 1) / 2, 1}, torch::TensorOptions().dtype(torch::kUInt8).device(W.device()));
+    torch::Tensor absmax = torch::empty({(n + blocksize - 1) / blocksize}, torch::TensorOptions().dtype(torch::kFloat32).device(W.device()));
+    c10::DeviceGuard guard(W.device());
+    check_status(fp4_hip_quantize_blockwise(W.data_ptr(), dt, packed.data_ptr<uint8_t>(), absmax.data_ptr<float>(), n, blocksize,
+                                            current_stream(W)));
+    return {packed, absmax};
+}
+
+torch::Tensor code_table(const std::string &name) {
+    TORCH_CHECK(name == "codebook" || name == "tree", "code_table: name must be 'codebook' or 'tree'");
+    torch::Tensor t = torch::empty({16}, torch::kFloat32);
+    check_status(fp4_hip_code_table(name == "tree" ? FP4_TABLE_TREE : FP4_TABLE_CODEBOOK, t.data_ptr<float>()));
+    return t;
+}
+
+void set_kernel_variant(const std::string &kernel, int variant) { check_status(fp4_hip_set_variant(kernel.c_str(), variant)); }
+
+}  // namespace
+
+PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
+    m.doc() = "MI355X (gfx950) FP4 dequant / fused GEMV operators; same surface as aredden/torch-bnb-fp4's torch_bnb_fp4_ext";
+    pybind11::enum_<ScalarTypeEnum>(m, "ScalarType")
+        .value("bfloat16", ScalarTypeEnum::bfloat16)
+        .value("float16", ScalarTypeEnum::float16)
+        .value("float32", ScalarTypeEnum::float32)
+        .export_values();
+
+    m.def("dequantize_fp4", &dequantize_fp4, "FP4 -> T dequant, tree constants: (A, absmax, blocksize, M, N, o_type)");
+    m.def("dequantize_fp4_codebook", &dequantize_fp4_codebook,
+          "FP4 -> T dequant, CODE_PARAM table: (A, absmax, codebook, M, N, blocksize, n, dtype)");
+    m.def("gemv_fp4", &gemv_fp4, "fused batch-1 FP4 GEMV: (A, B, absmax, datatype, blocksize, dtype, Bshape)");
+    m.def("qlinear", &qlinear, "tree dequant + linear: (A_in, A, absmax, M, N, blocksize)");
+    m.def("qlinear_bias", &qlinear_bias, "tree dequant + linear + bias");
+    m.def("qlinear_codebook", &qlinear_codebook, "codebook dequant + linear: (A_in, A, absmax, codebook, M, N, blocksize)");
+    m.def("qlinear_codebook_bias", &qlinear_codebook_bias, "codebook dequant + linear + bias");
+    // extras
+    m.def("gemv_fp4_bias", &gemv_fp4_bias, "gemv_fp4 with the bias add fused into the epilogue");
+    m.def("quantize_fp4", &quantize_fp4, "blockwise FP4 quantiser: (W, blocksize) -> (packed, absmax)");
+    m.def("code_table", &code_table, "16-entry code table as a CPU float tensor");
+    m.def("set_kernel_variant", &set_kernel_variant, "benchmark hook: select a kernel geometry");
+    m.attr("abi_version") = fp4_hip_abi_version();
+}

@@ -1,0 +1,60 @@
+"""``TorchFP4Linear``: nn.Module shell around :class:`QuantData`.
+
+Counterpart of the reference's class of the same name (torch_bnb_fp4/__init__.py:621-714).
+Unlike the reference, which hides the wrapped layer in a python list so that nothing is
+registered (:644), the packed weight, scales and bias are registered buffers here, so
+``state_dict()`` round-trips and ``.to(device)`` moves the layer.
+"""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+from .nn import is_fp4_params
+from .quant_data import QuantData
+
+
+class TorchFP4Linear(nn.Module):
+    def __init__(self, lin, use_codebook_dequant: bool = True, name: str = ""):
+        super().__init__()
+        self.lin = [lin]  # kept out of module registration, like the reference
+        self.in_features = lin.in_features
+        self.out_features = lin.out_features
+        self.use_codebook_dequant = use_codebook_dequant
+        self.name = name
+        w = lin.weight
+        if not is_fp4_params(w):
+            raise ValueError("Linear is not a bnb linear and is not quantized, and I have no idea what to do with that rn.")
+        if getattr(w, "quant_state", None) is None or w.device.type != "cuda" or w.data.dtype != torch.uint8:
+            raise ValueError(
+                f"Linear weights are not quantized, and I have no idea what to do with that rn. Weights are {w.data.dtype}")
+        self.quant_data = QuantData(w.data, w.quant_state, w.quant_state.shape, bias=lin.bias, original_lin=lin,
+                                    use_codebook_dequant=self.use_codebook_dequant)
+        self.register_buffer("qweight", self.quant_data.A, persistent=True)
+        self.register_buffer("absmax", self.quant_data.absmax, persistent=True)
+        self.register_buffer("code", self.quant_data.code, persistent=True)
+        self.register_buffer("bias", None if self.quant_data.bias is None else self.quant_data.bias.detach(), persistent=True)
+
+    def _apply(self, fn, recurse=True):
+        # only device moves are honoured: the packed bytes and f32 scales never change dtype
+        probe = fn(torch.empty(0, dtype=torch.float16, device=self.qweight.device))
+        if probe.device != self.qweight.device:
+            mv = lambda t: None if t is None else t.to(probe.device)
+            self.qweight, self.absmax, self.code, self.bias = mv(self.qweight), mv(self.absmax), mv(self.code), mv(self.bias)
+            qd = self.quant_data
+            qd.A, qd.absmax, qd.code = self.qweight, self.absmax, self.code
+            qd.bias = None if qd.bias is None else qd.bias.to(probe.device)
+        return self
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return self.quant_data.forward(x)
+
+    def __repr__(self) -> str:
+        dt = getattr(getattr(self, "quant_data", None), "o_type", None)
+        return (f"TorchFP4Linear(in_features={self.in_features}, out_features={self.out_features}, "
+                f"bias={self.lin[0].bias is not None}" + (f", dtype={dt})" if hasattr(self, "quant_data") else ")"))
+
+    @classmethod
+    def from_linear(cls, linear, use_codebook_dequant: bool = False, name: str = "") -> "TorchFP4Linear":
+        """Wrap an already-quantised FP4 layer (note the reference's default of ``False`` here, :699)."""
+        return cls(linear, use_codebook_dequant=use_codebook_dequant, name=name)

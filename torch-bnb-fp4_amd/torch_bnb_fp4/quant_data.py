@@ -1,0 +1,112 @@
+"""``QuantData``: the packed weight of one Linear plus the GEMV / dequant+GEMM dispatcher.
+
+Counterpart of the reference's ``QuantData`` (torch_bnb_fp4/__init__.py:340-618); the dispatch
+rules of ``forward`` are part of the parity contract and are reproduced branch for branch:
+
+====================================  =========================================
+input                                 path
+====================================  =========================================
+any dim of size 0                     empty tensor of the output shape (:580-589)
+numel == last dim, K % blocksize != 0 ``qlinear``                        (:593-594)
+numel == last dim, 2-D or 3-D         fused GEMV, bias added after       (:603-613)
+numel == last dim, other ranks        ``qlinear``                        (:614-615)
+everything else (batch or seq > 1)    ``qlinear`` = dequant + F.linear   (:616-617)
+====================================  =========================================
+"""
+from __future__ import annotations
+
+from math import prod
+from typing import Optional, Tuple
+
+import torch
+
+from ._ext import ext
+from .dtypes import ScalarType
+from .functional import dequantize_fp4_codebook_invoke_qtype, dequantize_fp4_qtype, gemm_4bit_inference_qtype
+
+
+class QuantData:
+    def __init__(self, A: torch.Tensor, state, shape: Tuple[int, int], original_lin=None,
+                 bias: Optional[torch.Tensor] = None, use_codebook_dequant: Optional[bool] = True,
+                 allow_reduced_precision_linear: Optional[bool] = False, fuse_bias: bool = True):
+        self.use_codebook_dequant = use_codebook_dequant
+        self.A = A
+        self.absmax = state.absmax.float()
+        self.blocksize = state.blocksize
+        self.M, self.N = shape[0], shape[1]
+        self.code = state.code.float()
+        self.o_type = None
+        self.qtype = None
+        self.quant_state = state
+        # same precedence as the reference (:387): the wrapped layer's bias wins over the argument
+        self.bias = original_lin.bias if hasattr(original_lin, "bias") else bias
+        self.original_lin = original_lin
+        self.compute_dtype_set = False
+        self.numel = prod(shape)
+        # fuse the post-GEMV `out += bias` into the kernel epilogue (bit-identical, one launch fewer)
+        self.fuse_bias = fuse_bias
+        if allow_reduced_precision_linear:
+            self.qlinear = self._qlinear_low_precision_codebook if use_codebook_dequant else self._qlinear_low_precision_normal
+        else:
+            self.qlinear = self._dequant_linear
+        self.dequantize = self._dequantize_codebook if use_codebook_dequant else self._dequantize_normal
+
+    # -- compute dtype ---------------------------------------------------------------------------
+    def set_compute_type(self, x: torch.Tensor) -> None:
+        """First call fixes the compute dtype to the activation's and casts the bias to it (:403-421)."""
+        self.o_type = x.dtype
+        self.qtype = ScalarType.from_torch_dtype(x.dtype).value
+        if self.bias is not None:
+            self.bias = self.bias.to(dtype=self.o_type)
+        self.compute_dtype_set = True
+
+    # -- dequant ---------------------------------------------------------------------------------
+    def _dequantize_codebook(self) -> torch.Tensor:
+        return dequantize_fp4_codebook_invoke_qtype(self.A, self.absmax, self.code, self.blocksize, self.M, self.N,
+                                                    self.numel, self.qtype)
+
+    def _dequantize_normal(self) -> torch.Tensor:
+        return dequantize_fp4_qtype(self.A, self.absmax, self.blocksize, self.M, self.N, self.qtype)
+
+    def _dequant_linear(self, A: torch.Tensor) -> torch.Tensor:
+        return torch.nn.functional.linear(A, self.dequantize(), self.bias)
+
+    # -- fused paths -----------------------------------------------------------------------------
+    def _qgemv(self, A: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+        # the reference hands the packed [numel/2, 1] tensor over transposed (:486); it stays contiguous
+        return gemm_4bit_inference_qtype(A=A, B=self.A.t(), absmax=self.absmax, code=self.code, blocksize=self.blocksize,
+                                         dtype=self.qtype, Bshape=self.quant_state.shape, bias=bias)
+
+    def _qlinear_low_precision_normal(self, A: torch.Tensor) -> torch.Tensor:
+        if self.bias is None:
+            return ext.qlinear(A, self.A, self.absmax, self.M, self.N, self.blocksize)
+        return ext.qlinear_bias(A, self.A, self.absmax, self.M, self.N, self.blocksize, self.bias)
+
+    def _qlinear_low_precision_codebook(self, A: torch.Tensor) -> torch.Tensor:
+        if self.bias is None:
+            return ext.qlinear_codebook(A, self.A, self.absmax, self.code, self.M, self.N, self.blocksize)
+        return ext.qlinear_codebook_bias(A, self.A, self.absmax, self.code, self.M, self.N, self.blocksize, self.bias)
+
+    # -- dispatcher ------------------------------------------------------------------------------
+    def forward(self, A: torch.Tensor) -> torch.Tensor:
+        total = prod(A.shape)
+        if total == 0:
+            w_shape = self.quant_state.shape
+            tail = w_shape[1:] if A.shape[-1] == w_shape[0] else w_shape[:1]
+            return torch.empty(A.shape[:-1] + tail, dtype=A.dtype, device=A.device)
+        if not self.compute_dtype_set:
+            self.set_compute_type(A)
+        K = A.shape[-1]
+        single_token = total == K
+        if not single_token or K % self.blocksize != 0 or A.ndim not in (2, 3):
+            return self.qlinear(A)
+        if not A.is_contiguous():
+            A = A.contiguous()
+        lead = A.shape[0]
+        fused = self.bias if self.fuse_bias else None
+        out = self._qgemv(A.view(-1, K), fused)
+        if A.ndim == 3:
+            out = out.view(lead, 1, -1)
+        if self.bias is not None and fused is None:
+            out += self.bias
+        return out

@@ -1,0 +1,127 @@
+"""Model surgery: nn.Linear -> FP4 layer -> :class:`TorchFP4Linear`.
+
+Counterpart of the reference's module-walking helpers (torch_bnb_fp4/__init__.py:717-922) with
+the same names, keyword arguments and defaults.  The nn.Linear -> FP4 step, which the reference
+delegates to bitsandbytes (``bnb.nn.LinearFP4`` + ``Params4bit.cuda()``), uses this package's own
+:class:`~torch_bnb_fp4.nn.LinearFP4` and HIP quantiser, so no bitsandbytes install is needed.
+"""
+from __future__ import annotations
+
+import logging
+from typing import List, Optional, TypeVar
+
+import torch
+from torch import nn
+
+from .functional import quantize_fp4
+from .linear import TorchFP4Linear
+from .nn import FP4_LINEAR_TYPES, LinearFP4, Params4bit, QuantState, fp4_code
+
+T_Model = TypeVar("T_Model", bound=nn.Module)
+log = logging.getLogger(__name__)
+
+
+@torch.no_grad()
+def swap_linear_with_bnb_linear(linear: nn.Linear, dtype=torch.float16) -> LinearFP4:
+    """New (still dense) ``LinearFP4`` holding clones of ``linear``'s weight and bias; it quantises
+    when moved to a GPU (reference :717-747)."""
+    fp4 = LinearFP4(input_features=linear.in_features, output_features=linear.out_features,
+                    bias=linear.bias is not None, compute_dtype=dtype)
+    fp4.weight = Params4bit(linear.weight.data.clone().detach(), False, None, fp4.blocksize, "fp4")
+    if linear.bias is not None:
+        fp4.bias.data = linear.bias.data.clone().detach()
+    fp4.requires_grad_(False)
+    return fp4
+
+
+def check_if_name_contained_in_list(name: str, names_list) -> bool:
+    """True when any entry of ``names_list`` is a substring of ``name`` (reference :750-756)."""
+    return any(entry in name for entry in names_list)
+
+
+def todevice_if_necessary(module, device):
+    """Make sure an FP4 layer's weight really is packed uint8 on ``device``; quantise it directly
+    if moving the module did not (reference :759-778)."""
+    if module.weight.data.dtype != torch.uint8 and isinstance(module, FP4_LINEAR_TYPES):
+        module = module.to(device)
+        w = module.weight
+        if not (w.data.device == torch.device(device) and w.data.dtype == torch.uint8):
+            log.debug("layer was not quantised by the device move; quantising its weight directly")
+            dense = w.data.to(device=device, dtype=torch.float16)
+            packed, absmax = quantize_fp4(dense, module.blocksize)
+            state = QuantState(absmax, dense.shape, fp4_code().to(device), module.blocksize, w.data.dtype)
+            module.weight = Params4bit(packed, False, state, module.blocksize, "fp4")
+    return module
+
+
+def _device_is_gpu(device) -> bool:
+    kind = device.type if hasattr(device, "type") else str(device).split(":")[0]
+    return kind == "cuda"
+
+
+def _to_fp4_linear(layer: nn.Module, device, as_dtype, use_codebook_dequant: bool, name: str) -> TorchFP4Linear:
+    """nn.Linear or FP4 layer -> TorchFP4Linear on ``device``."""
+    if not isinstance(layer, FP4_LINEAR_TYPES):
+        layer = swap_linear_with_bnb_linear(layer, dtype=as_dtype)
+    layer = layer.to(device)
+    if getattr(layer.weight, "quant_state", None) is None:
+        layer = todevice_if_necessary(layer, device)
+    return TorchFP4Linear(lin=layer, use_codebook_dequant=use_codebook_dequant, name=name)
+
+
+def recursively_replace_with_fp4_linear(
+    module: T_Model,
+    as_dtype=torch.float16,
+    use_codebook_dequant=True,
+    device: torch.device = torch.device("cuda" if torch.cuda.is_available() else "cpu"),
+    return_final_module: bool = True,
+    only_replace_bnb_layers: bool = False,
+    ignore_layer_names: List[str] = ["lm_head"],
+    parent="",
+    debug: bool = False,
+) -> Optional[T_Model]:
+    """Replace every nn.Linear / FP4 linear below ``module`` by a :class:`TorchFP4Linear`.
+
+    Same contract as the reference (:781-922): children whose *own* name contains an entry of
+    ``ignore_layer_names`` are skipped together with their subtree; ``only_replace_bnb_layers``
+    leaves plain nn.Linear alone; a root that is itself a Linear is converted and returned;
+    ``named_children()`` dedupes shared modules, so a Linear object reused in several slots is
+    swapped only in the first one (the reference's sanity model relies on exactly that).
+    """
+    assert _device_is_gpu(device), "Device type must be cuda!"
+    prefix = parent + "." if parent != "" else ""
+    swapped_dense = False
+    for name, child in module.named_children():
+        child_name = prefix + name
+        if check_if_name_contained_in_list(name, ignore_layer_names):
+            if debug:
+                print(f"Ignoring name: {child_name}, as it is in the ignore list")
+            continue
+        if isinstance(child, (nn.Linear,) + FP4_LINEAR_TYPES):
+            is_fp4 = isinstance(child, FP4_LINEAR_TYPES)
+            if not is_fp4 and only_replace_bnb_layers:
+                if debug:
+                    print(f"Ignoring {child_name}, as only_replace_bnb_layers=True")
+                continue
+            if debug:
+                print(f"Replacing {'FP4 layer ' if is_fp4 else ''}{child_name} with TorchFP4Linear.")
+            module._modules[name] = _to_fp4_linear(child, device, as_dtype, use_codebook_dequant, child_name)
+            swapped_dense |= not is_fp4
+        elif isinstance(child, nn.Module):
+            recursively_replace_with_fp4_linear(child, as_dtype=as_dtype, use_codebook_dequant=use_codebook_dequant,
+                                                device=device, return_final_module=False,
+                                                only_replace_bnb_layers=only_replace_bnb_layers,
+                                                ignore_layer_names=ignore_layer_names, parent=child_name, debug=debug)
+    if isinstance(module, (nn.Linear,) + FP4_LINEAR_TYPES):
+        is_fp4 = isinstance(module, FP4_LINEAR_TYPES)
+        if is_fp4 or not only_replace_bnb_layers:
+            if debug:
+                print(f"Replacing {parent} with TorchFP4Linear.")
+            module = _to_fp4_linear(module, device, as_dtype, use_codebook_dequant, parent)
+            swapped_dense |= not is_fp4
+        elif debug:
+            print(f"Ignoring {parent}, as only_replace_bnb_layers=True")
+    if swapped_dense:
+        torch.cuda.empty_cache()  # the dense copies are gone; give their blocks back (:919-920)
+    if return_final_module:
+        return module
