@@ -1,0 +1,318 @@
+#!/usr/bin/env python3
+"""Headline benchmark: FP4 dequant GB/s (% of HBM peak) + fused-GEMV us/layer, 4096x4096 bf16.
+
+One "step" = one pass of the hot path over a batch of R distinct 4096x4096 FP4 weight matrices
+(blocksize 64): R blockwise dequants to bf16, then GEMV_REPS x R fused batch-1 GEMVs, every launch
+through the C ABI of libtorch_bnb_fp4_hip.so.  The R matrices (R x 9.4 MB packed+scales, R x 32 MiB
+of outputs) rotate through far more than the 256 MiB Infinity Cache, so every launch streams from
+HBM ("HBM-cold"); same-buffer "hot" figures are reported separately.  Launches are replayed from
+HIP graphs so the host never paces the GPU; the timed region still contains one kernel boundary
+per launch, exactly as a decode loop would.
+
+Contract: `python bench.py --gpus N --steps K --warmup W` (N > 1 under torchrun, one rank per GPU);
+W untimed warm-up steps, then exactly K timed steps between barrier + synchronize, MAX over ranks,
+rank 0 prints ONE JSON line.  `value` = whole-job dequant GB/s (algorithmic bytes, inputs resident
+in HBM); the GEMV figures, the HIP-event roofline of the dequant kernel and a pure-torch CPU
+dequant baseline timed on the host cores ride along in the same line.  No data-path collective:
+rows of W are independent, so ranks process independent shards (weak scaling).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import statistics
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+for _p in (REPO, os.path.join(REPO, "torch-bnb-fp4_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch  # noqa: E402
+
+M = K = 4096
+BLOCKSIZE = 64
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy rate is reported next to it
+F16, F32, BF16 = 0, 1, 2
+
+
+def dequant_bytes(m, k, bs, itemsize):
+    return m * k // 2 + 4 * (m * k // bs) + m * k * itemsize
+
+
+def gemv_bytes(m, k, bs, itemsize):
+    return m * k // 2 + 4 * (m * k // bs) + k * itemsize + m * itemsize
+
+
+class Lib:
+    """The product library, bound through its C ABI (include/torch_bnb_fp4_hip.h)."""
+
+    def __init__(self):
+        import torch_bnb_fp4  # product package: fails loudly if the HIP extension is missing
+
+        self.pkg = torch_bnb_fp4
+        self.l = ctypes.CDLL(torch_bnb_fp4.HIP_LIBRARY_PATH)
+        vp, i32, i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
+        self.l.fp4_hip_dequantize_blockwise.argtypes = [vp, vp, vp, i32, i64, i32, i32, vp]
+        self.l.fp4_hip_gemv.argtypes = [vp, vp, vp, vp, vp, i64, i64, i32, i32, vp]
+        self.l.fp4_hip_last_error.restype = ctypes.c_char_p
+
+    def _check(self, rc):
+        if rc != 0:
+            raise RuntimeError(self.l.fp4_hip_last_error().decode())
+
+    def dequant(self, packed, absmax, out, n, dtype=BF16):
+        s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        self._check(self.l.fp4_hip_dequantize_blockwise(packed.data_ptr(), absmax.data_ptr(), out.data_ptr(), BLOCKSIZE, n, dtype, 0, s))
+
+    def gemv(self, x, packed, absmax, out, m, k, dtype=BF16):
+        s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        self._check(self.l.fp4_hip_gemv(x.data_ptr(), packed.data_ptr(), absmax.data_ptr(), None, out.data_ptr(), m, k, BLOCKSIZE, dtype, s))
+
+
+def capture(fn):
+    """Capture fn() into a HIP graph (after one eager run) and return a replay callable."""
+    fn()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        fn()
+    torch.cuda.synchronize()
+    return g.replay
+
+
+def time_replays(replay, reps, launches):
+    """Median us per launch over `reps` event-timed replays of a graph holding `launches` kernels."""
+    out = []
+    for _ in range(reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        replay()
+        b.record()
+        b.synchronize()
+        out.append(a.elapsed_time(b) * 1e3 / launches)
+    return statistics.median(out), out
+
+
+def cpu_baseline(budget_s=12.0):
+    """Pure-torch dequant of the same 4096x4096 -> bf16 problem on the host cores."""
+    from oracle import torch_cpu
+
+    ncores = os.cpu_count() or 1
+    torch.set_num_threads(ncores)
+    g = torch.Generator().manual_seed(0)
+    packed = torch.randint(0, 256, (M * K // 2,), dtype=torch.uint8, generator=g)
+    absmax = torch.rand(M * K // BLOCKSIZE, generator=g) * 0.1 + 0.01
+    table = torch_cpu.code_table()
+    times = []
+    t_end = time.perf_counter() + budget_s
+    for i in range(13):
+        t0 = time.perf_counter()
+        torch_cpu.dequantize(packed, absmax, M, K, BLOCKSIZE, torch.bfloat16, table)
+        dt = time.perf_counter() - t0
+        if i >= 3 or time.perf_counter() > t_end:
+            times.append(dt)
+        if time.perf_counter() > t_end and times:
+            break
+    med = statistics.median(times)
+    x = torch.randn(1, K)
+    t0 = time.perf_counter()
+    torch_cpu.gemv(x, packed, absmax, M, K, BLOCKSIZE)
+    gemv_s = time.perf_counter() - t0
+    return {
+        "value": round(dequant_bytes(M, K, BLOCKSIZE, 2) / med / 1e9, 3),
+        "unit": "GB/s",
+        "cores": torch.get_num_threads(),
+        "kind": "port",
+        "sample": f"{len(times)} timed pure-torch CPU dequants of one 4096x4096 bs64 weight to bf16 (median {med * 1e3:.1f} ms; "
+                  f"os.cpu_count()={ncores}, torch threads={torch.get_num_threads()}); CPU dequant+GEMV once: {gemv_s * 1e3:.1f} ms",
+        "ms_per_matrix": round(med * 1e3, 3),
+        "gemv_us_per_layer": round(gemv_s * 1e6, 1),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--matrices", type=int, default=64, help="distinct 4096x4096 FP4 weights per step (R)")
+    ap.add_argument("--gemv-reps", type=int, default=4, help="GEMV passes over the R weights per step")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        sys.exit(f"--gpus {args.gpus} needs torchrun with --nproc-per-node {args.gpus} (WORLD_SIZE={world})")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    lib = Lib()
+    R, GR = args.matrices, args.gemv_reps
+    n = M * K
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    packed = [torch.randint(0, 256, (n // 2,), dtype=torch.uint8, device=dev, generator=gen) for _ in range(R)]
+    absmax = [torch.rand(n // BLOCKSIZE, device=dev, generator=gen) * 0.1 + 0.01 for _ in range(R)]
+    outs = [torch.empty(n, dtype=torch.bfloat16, device=dev) for _ in range(R)]
+    x = torch.randn(K, device=dev, generator=gen).to(torch.bfloat16)
+    ys = [torch.empty(M, dtype=torch.bfloat16, device=dev) for _ in range(R)]
+
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        def dq_pass():
+            for i in range(R):
+                lib.dequant(packed[i], absmax[i], outs[i], n)
+
+        def gv_pass():
+            for _ in range(GR):
+                for i in range(R):
+                    lib.gemv(x, packed[i], absmax[i], ys[i], M, K)
+
+        dq_replay = capture(dq_pass)
+        gv_replay = capture(gv_pass)
+
+        def barrier():
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+
+        for _ in range(args.warmup):
+            dq_replay()
+            gv_replay()
+        barrier()
+        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+        t0 = time.perf_counter()
+        for s in range(args.steps):
+            ev[s][0].record()
+            dq_replay()
+            ev[s][1].record()
+            gv_replay()
+            ev[s][2].record()
+        barrier()
+        wall = time.perf_counter() - t0
+        dq_ms = [e[0].elapsed_time(e[1]) for e in ev]
+        gv_ms = [e[1].elapsed_time(e[2]) for e in ev]
+        dq_total_s, gv_total_s = sum(dq_ms) / 1e3, sum(gv_ms) / 1e3
+
+        # ---- secondary figures (outside the timed region) ------------------------------------
+        extra = {}
+        if rank == 0:
+            hot_dq = capture(lambda: [lib.dequant(packed[0], absmax[0], outs[0], n) for _ in range(32)])
+            hot_gv = capture(lambda: [lib.gemv(x, packed[0], absmax[0], ys[0], M, K) for _ in range(128)])
+            extra["dequant_hot_us"] = round(time_replays(hot_dq, 10, 32)[0], 3)
+            extra["gemv_hot_us"] = round(time_replays(hot_gv, 10, 128)[0], 3)
+            # comparator for the "fused GEMV faster than dequant + hipBLASLt GEMV" target, same inputs
+            x2 = x.view(1, K)
+            def dq_gemm():
+                for i in range(R):
+                    lib.dequant(packed[i], absmax[i], outs[i], n)
+                    torch.nn.functional.linear(x2, outs[i].view(M, K))
+            extra["dequant_plus_hipblaslt_gemv_us"] = round(time_replays(capture(dq_gemm), 5, R)[0], 3)
+            def gemm_only():
+                for i in range(R):
+                    torch.nn.functional.linear(x2, outs[i].view(M, K))
+            extra["hipblaslt_gemv_bf16_dense_us"] = round(time_replays(capture(gemm_only), 5, R)[0], 3)
+            # other dtypes / table, HBM-cold, for the record
+            for name, dt, tdt in (("f16", F16, torch.float16), ("f32", F32, torch.float32)):
+                o32 = [torch.empty(n, dtype=tdt, device=dev) for _ in range(16)]
+                rp = capture(lambda: [lib.dequant(packed[i], absmax[i], o32[i % 16], n, dt) for i in range(R)])
+                us = time_replays(rp, 5, R)[0]
+                extra[f"dequant_{name}_us"] = round(us, 3)
+                extra[f"dequant_{name}_gbps"] = round(dequant_bytes(M, K, BLOCKSIZE, o32[0].element_size()) / us / 1e3, 1)
+                del o32, rp
+            # end-to-end through the Python op surface (host overhead visible, like the reference's README table)
+            code = lib.pkg.ext.code_table("tree").to(dev)
+            B = packed[0].view(-1, 1).t()
+            for _ in range(20):
+                lib.pkg.gemm_4bit_inference(x2, B, absmax[0], code, BLOCKSIZE, torch.bfloat16, [M, K])
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(200):
+                lib.pkg.gemm_4bit_inference(x2, B, absmax[0], code, BLOCKSIZE, torch.bfloat16, [M, K])
+            torch.cuda.synchronize()
+            extra["gemv_python_op_us"] = round((time.perf_counter() - t1) / 200 * 1e6, 2)
+            # device copy rate of this box, the practical HBM ceiling
+            src = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+            dst = torch.empty_like(src)
+            cp = capture(lambda: dst.copy_(src))
+            us = time_replays(cp, 5, 1)[0]
+            extra["device_copy_gbps"] = round(2 * src.numel() / us / 1e3, 1)
+            del src, dst
+
+    times = torch.tensor([wall, dq_total_s, gv_total_s], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(times, op=dist.ReduceOp.MAX)
+    wall, dq_total_s, gv_total_s = times.tolist()
+
+    if rank == 0:
+        dq_b, gv_b = dequant_bytes(M, K, BLOCKSIZE, 2), gemv_bytes(M, K, BLOCKSIZE, 2)
+        dq_launches, gv_launches = args.steps * R, args.steps * R * GR
+        dq_us, gv_us = dq_total_s * 1e6 / dq_launches, gv_total_s * 1e6 / gv_launches
+        dq_gbps_gpu = dq_b / dq_us / 1e3
+        gv_gbps_gpu = gv_b / gv_us / 1e3
+        line = {
+            "metric": "FP4 dequant GB/s (% HBM peak) + fused-GEMV us/layer, 4096x4096 bf16",
+            "value": round(dq_gbps_gpu * world, 1),
+            "unit": "GB/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(wall * 1e3 / args.steps, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "bf16",
+            "data": "synthetic",
+            "config": {
+                "workload": f"FP4 4096x4096 blocksize 64 -> bf16: per step {R} distinct weights, each dequantised once and "
+                            f"GEMV'd {GR}x (batch 1), HBM-cold rotation over {R * (dq_b) / 1e9:.2f} GB, HIP-graph replay",
+                "M": M, "K": K, "blocksize": BLOCKSIZE, "matrices_per_step": R, "gemv_passes_per_step": GR,
+                "parallelism": f"independent row shards x{world}, no collective",
+            },
+            "pct_hbm_peak": round(100 * dq_gbps_gpu / HBM_PEAK_GBPS, 2),
+            "dequant_us_per_matrix": round(dq_us, 3),
+            "gemv_us_per_layer": round(gv_us, 3),
+            "gemv_gbps": round(gv_gbps_gpu * world, 1),
+            "gemv_pct_hbm_peak": round(100 * gv_gbps_gpu / HBM_PEAK_GBPS, 2),
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "dequant_tiles_kernel<bf16> (fp4_hip_dequantize_blockwise)",
+                "achieved": round(dq_gbps_gpu, 1),
+                "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s",
+                "frac": round(dq_gbps_gpu / HBM_PEAK_GBPS, 4),
+                "traffic": None,
+                "bytes_per_launch": dq_b,
+                "avg_launch_us": round(dq_us, 3),
+                "method": "HIP events around each graph replay of R back-to-back launches on the launch stream; "
+                          "includes one kernel boundary per launch (rocprofv3 kernel durations: profiles/)",
+            },
+            "roofline_gemv": {
+                "bound": "hbm", "kernel": "gemv16_kernel<bf16> (fp4_hip_gemv)", "achieved": round(gv_gbps_gpu, 1),
+                "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(gv_gbps_gpu / HBM_PEAK_GBPS, 4), "traffic": None,
+                "bytes_per_launch": gv_b, "avg_launch_us": round(gv_us, 3),
+            },
+        }
+        line.update(extra)
+        if "dequant_plus_hipblaslt_gemv_us" in extra:
+            line["fused_gemv_speedup_vs_dequant_hipblaslt"] = round(extra["dequant_plus_hipblaslt_gemv_us"] / gv_us, 2)
+        if world == 1 and not args.no_cpu:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,50 @@
+"""The C-ABI library loads and exports exactly what include/torch_bnb_fp4_hip.h declares; argument
+validation (which returns before any HIP call) behaves as documented.  No GPU needed."""
+import ctypes
+import subprocess
+
+import numpy as np
+
+import hipabi
+from oracle import fp4_oracle as o
+
+
+def test_header_symbols_are_exported():
+    declared = hipabi.declared_symbols()
+    assert set(declared) >= {"fp4_hip_abi_version", "fp4_hip_last_error", "fp4_hip_code_table", "fp4_hip_dequantize_blockwise",
+                             "fp4_hip_gemv", "fp4_hip_quantize_blockwise", "fp4_hip_set_variant"}
+    l = hipabi.lib()
+    for name in declared:
+        assert hasattr(l, name), name
+    # and nothing else leaks out of the library (built with -fvisibility=hidden)
+    nm = subprocess.run(["nm", "-D", "--defined-only", hipabi.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in nm.splitlines() if " T " in ln}
+    assert exported == set(declared), exported ^ set(declared)
+
+
+def test_abi_version_and_tables():
+    l = hipabi.lib()
+    assert l.fp4_hip_abi_version() == 1
+    for which, tab in ((hipabi.TABLE_CODEBOOK, o.CODEBOOK_TABLE), (hipabi.TABLE_TREE, o.TREE_TABLE)):
+        out = np.zeros(16, np.float32)
+        assert l.fp4_hip_code_table(which, out.ctypes.data_as(ctypes.c_void_p)) == hipabi.OK
+        assert (out.view(np.uint32) == tab.view(np.uint32)).all()
+    assert l.fp4_hip_code_table(7, None) == hipabi.ERR_INVALID
+
+
+def test_argument_validation_without_gpu():
+    l = hipabi.lib()
+    one = ctypes.c_void_p(16)  # never dereferenced: validation fails first
+    assert l.fp4_hip_dequantize_blockwise(one, one, one, 64, -1, hipabi.F16, 0, None) == hipabi.ERR_INVALID
+    assert l.fp4_hip_dequantize_blockwise(one, one, one, 63, 128, hipabi.F16, 0, None) == hipabi.ERR_INVALID
+    assert "blocksize" in hipabi.last_error()
+    assert l.fp4_hip_dequantize_blockwise(one, one, one, 64, 128, hipabi.F16, 5, None) == hipabi.ERR_INVALID
+    assert l.fp4_hip_dequantize_blockwise(None, one, one, 64, 128, hipabi.F16, 0, None) == hipabi.ERR_INVALID
+    assert l.fp4_hip_dequantize_blockwise(one, one, one, 64, 128, 9, 0, None) == hipabi.ERR_UNSUPPORTED
+    assert l.fp4_hip_dequantize_blockwise(None, None, None, 64, 0, hipabi.F16, 0, None) == hipabi.OK  # empty input
+    assert l.fp4_hip_gemv(one, one, one, None, one, 4, 63, 64, hipabi.BF16, None) == hipabi.ERR_INVALID  # odd K
+    assert l.fp4_hip_gemv(one, one, one, None, one, 4, 64, 64, 9, None) == hipabi.ERR_UNSUPPORTED
+    assert l.fp4_hip_gemv(None, None, None, None, None, 0, 64, 64, hipabi.BF16, None) == hipabi.OK  # M == 0
+    assert l.fp4_hip_quantize_blockwise(one, hipabi.F16, one, one, 64, 48, None) == hipabi.ERR_UNSUPPORTED
+    assert l.fp4_hip_set_variant(b"nope", 1) == hipabi.ERR_INVALID
+    assert l.fp4_hip_set_variant(b"gemv", -1) == hipabi.OK

@@ -1,0 +1,148 @@
+"""GPU parity of the HIP dequant kernels, called through the C ABI: bit-exact against the oracle
+and the committed golden vectors (integer/byte work and one f32 multiply + RNE: no tolerance)."""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+import hipabi
+from gpu_util import NPDT, bits, dev, np_bits, to_dev
+from oracle import c_oracle, fp4_oracle as o
+
+pytestmark = pytest.mark.gpu
+DTYPES = [torch.float32, torch.float16, torch.bfloat16]
+TABLES = [("codebook", hipabi.TABLE_CODEBOOK), ("tree", hipabi.TABLE_TREE)]
+
+
+@pytest.fixture(autouse=True)
+def _default_variant():
+    hipabi.set_variant("dequant", -1)
+    yield
+    hipabi.set_variant("dequant", -1)
+
+
+def test_exhaustive_bytes_and_absmax_index(golden):
+    for name, tb in TABLES:
+        out = hipabi.dequantize(to_dev(golden["kat1_packed"]), torch.ones(8, device=dev()), 64, 512, torch.float32, tb)
+        assert (bits(out) == np_bits(golden[f"kat1_{name}_f32"])).all()
+    for bs in (64, 128, 32, 256):
+        want = golden[f"kat2_bs{bs}_f32"]
+        out = hipabi.dequantize(to_dev(golden[f"kat2_bs{bs}_packed"]), to_dev(golden[f"kat2_bs{bs}_absmax"]), bs, want.size,
+                                torch.float32)
+        assert (bits(out) == np_bits(want)).all()
+
+
+@pytest.mark.parametrize("name,tb", TABLES)
+@pytest.mark.parametrize("dtype,key", [(torch.float32, "f32"), (torch.float16, "f16"), (torch.bfloat16, "bf16")])
+def test_rounding_kat_ties_subnormals_sweep(golden, name, tb, dtype, key):
+    am = golden["kat3_absmax"]
+    out = hipabi.dequantize(to_dev(golden["kat3_packed"]), to_dev(am), 64, am.size * 64, dtype, tb)
+    want = golden[f"kat3_{name}_{key}"]
+    got = bits(out)
+    bad = np.nonzero(got != np_bits(want))[0]
+    assert bad.size == 0, (bad[:8], got[bad[:8]], np_bits(want)[bad[:8]], am[bad[:8] // 64])
+
+
+@pytest.mark.parametrize("tag", list("abcde"))
+def test_ragged_tails(golden, tag):
+    packed, am, n = golden[f"kat4{tag}_packed"], golden[f"kat4{tag}_absmax"], int(golden[f"kat4{tag}_n"])
+    h = hashlib.sha256()
+    for dt in DTYPES:
+        guard = torch.full((n + 64,), 7.0, dtype=dt, device=dev())  # canary behind the last element
+        hipabi.dequantize(to_dev(packed), to_dev(am), 64, n, dt, out=guard)
+        assert (guard[n:] == 7.0).all(), "wrote past n"
+        h.update(bits(guard[:n]).tobytes())
+    assert (np.frombuffer(h.digest(), np.uint8) == golden[f"kat4{tag}_sha256"]).all()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("variant", [-1, 1, 2, 4, 8, 16, 8 | 256, 2 | 256])
+def test_full_size_4096x4096_bit_exact_every_variant(dtype, variant):
+    M = K = 4096
+    n = M * K
+    rng = np.random.default_rng(100)
+    packed = rng.integers(0, 256, n // 2, dtype=np.uint8)
+    am = (rng.random(n // 64, dtype=np.float32) * 0.1 + 0.01).astype(np.float32)
+    want = np_bits(c_oracle.dequantize(packed, am, 64, n, NPDT[dtype]))
+    hipabi.set_variant("dequant", variant)
+    out = hipabi.dequantize(to_dev(packed), to_dev(am), 64, n, dtype)
+    torch.cuda.synchronize()
+    assert np.array_equal(bits(out), want)
+
+
+@pytest.mark.parametrize("bs", [32, 64, 128, 512, 1024, 4096, 16, 48, 2, 8192])
+def test_blocksizes_fast_and_generic(bs):
+    n = 3 * 8192 * 5 + 2 * 13  # not a multiple of any tile
+    rng = np.random.default_rng(bs)
+    packed = rng.integers(0, 256, (n + 1) // 2, dtype=np.uint8)
+    am = (rng.random(-(-n // min(bs, 16)) + 8, dtype=np.float32) + 0.5).astype(np.float32)
+    for dt in DTYPES:
+        for name, tb in TABLES:
+            want = np_bits(o.dequantize(packed, am, bs, n, NPDT[dt], name))
+            out = hipabi.dequantize(to_dev(packed), to_dev(am), bs, n, dt, tb)
+            assert np.array_equal(bits(out), want), (bs, dt, name)
+
+
+def test_unaligned_pointers_take_the_generic_path():
+    n = 70000
+    rng = np.random.default_rng(5)
+    packed = rng.integers(0, 256, n // 2 + 3, dtype=np.uint8)
+    am = (rng.random(n // 64 + 2, dtype=np.float32) + 0.1).astype(np.float32)
+    p = to_dev(packed)[3:]  # 3-byte offset
+    for dt in DTYPES:
+        out = torch.empty(n + 1, dtype=dt, device=dev())[1:]  # element offset -> not 16-byte aligned
+        hipabi.dequantize(p, to_dev(am), 64, n, dt, out=out)
+        assert np.array_equal(bits(out), np_bits(o.dequantize(packed[3:], am, 64, n, NPDT[dt])))
+
+
+def test_large_mlp_shape_and_checksum_property():
+    # Mistral/Llama gate/up/down shape (14336 x 4096): bit-exact vs the C oracle, and the
+    # size-independent property  dequant(all-0x33 bytes) == absmax broadcast
+    M, K = 14336, 4096
+    n = M * K
+    rng = np.random.default_rng(8)
+    packed = rng.integers(0, 256, n // 2, dtype=np.uint8)
+    am = (rng.random(n // 64, dtype=np.float32) * 0.05 + 0.001).astype(np.float32)
+    out = hipabi.dequantize(to_dev(packed), to_dev(am), 64, n, torch.bfloat16)
+    assert np.array_equal(bits(out), np_bits(c_oracle.dequantize(packed, am, 64, n, "bfloat16")))
+    ones = hipabi.dequantize(torch.full((n // 2,), 0x33, dtype=torch.uint8, device=dev()), to_dev(am), 64, n, torch.float32)
+    assert torch.equal(ones.view(-1, 64), to_dev(am)[:, None].expand(-1, 64))
+
+
+def test_torch_ext_ops_and_stream_semantics():
+    import torch_bnb_fp4 as pkg
+
+    M, K = 256, 384
+    rng = np.random.default_rng(11)
+    w = rng.standard_normal(M * K).astype(np.float32)
+    packed, am = o.quantize_fp4(w, 64)
+    A, absmax = to_dev(packed).view(-1, 1), to_dev(am)
+    code = pkg.ext.code_table("tree").to(dev())
+    for dt in DTYPES:
+        tree = pkg.dequantize_fp4(A, absmax, 64, M, K, dt)
+        cb = pkg.dequantize_fp4_codebook_invoke(A, absmax, code, 64, M, K, M * K, dt)
+        assert tree.shape == (M, K) and tree.dtype == dt and cb.shape == (M, K)
+        assert np.array_equal(bits(tree).reshape(-1), np_bits(o.dequantize(packed, am, 64, M * K, NPDT[dt], "tree")))
+        assert np.array_equal(bits(cb).reshape(-1), np_bits(o.dequantize(packed, am, 64, M * K, NPDT[dt], "codebook")))
+        qt = pkg.ScalarType.from_torch_dtype(dt).value
+        assert torch.equal(pkg.dequantize_fp4_qtype(A, absmax, 64, M, K, qt), tree)
+        assert torch.equal(pkg.dequantize_fp4_codebook_invoke_qtype(A, absmax, code, 64, M, K, M * K, qt), cb)
+    # `n` = number of elements to dequantise (reference csrc/torch_fp4.cpp:52-62): the rest is left alone
+    half = pkg.ext.dequantize_fp4_codebook(A, absmax, code, M, K, 64, M * K // 2, pkg.ScalarType.float32.value)
+    assert np.array_equal(bits(half).reshape(-1)[: M * K // 2], np_bits(o.dequantize(packed, am, 64, M * K // 2, "float32")))
+    # launches follow the current torch stream (the reference uses the legacy default stream)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        big = torch.randn(4096, 4096, device=dev())
+        for _ in range(8):
+            big = big @ big * 1e-3  # keep the side stream busy
+        absmax2 = absmax * 2.0  # produced on the side stream ...
+        out = pkg.dequantize_fp4(A, absmax2, 64, M, K, torch.float32)  # ... consumed by our kernel on the same stream
+    side.synchronize()
+    assert torch.equal(out, pkg.dequantize_fp4(A, absmax, 64, M, K, torch.float32) * 2.0)
+    # error behaviour
+    with pytest.raises(RuntimeError, match="contiguous"):
+        pkg.dequantize_fp4(to_dev(np.zeros((64, 2), np.uint8))[:, 0], absmax, 64, 8, 8, torch.float16)
+    with pytest.raises(RuntimeError, match="uint8"):
+        pkg.dequantize_fp4(absmax, absmax, 64, 1, 1, torch.float16)

@@ -1,0 +1,154 @@
+"""GPU parity of the fused FP4 GEMV through the C ABI.
+
+Floating-point work: tolerance-based (the reference's own GEMV is not bit-reproducible either: it
+accumulates per lane in half/bf16, csrc/gemv_fp4_optimized.cu:87,146-148).  Two bars, both written
+down here:
+
+1. closeness to the exact result  y* = x @ dequant_f32(W)^T  (float64, oracle.gemv_exact):
+   |y - y*| <= ulp_T(y*)/2 * 1.01 + 1e-5 * sum_k |x_k w_rk|      (one final rounding to T plus f32
+   accumulation noise; ulp_T/2 = 2^-8 |y| for bf16, 2^-11 |y| for fp16, 0 for f32);
+2. at least as close to y* as an emulation of the reference kernel's arithmetic
+   (oracle.gemv_reference_emulated), in mean absolute error.
+"""
+import numpy as np
+import pytest
+import torch
+
+import hipabi
+from gpu_util import NPDT, dev, to_dev, torch_values
+from oracle import c_oracle, fp4_oracle as o
+
+pytestmark = pytest.mark.gpu
+DTYPES = [torch.bfloat16, torch.float16, torch.float32]
+HALF_ULP = {torch.bfloat16: 2.0**-8, torch.float16: 2.0**-11, torch.float32: 0.0}
+VARIANTS16 = [r | (w << 8) | (u << 16) for (r, w, u) in
+              [(1, 4, 1), (1, 4, 2), (2, 4, 1), (2, 4, 2), (4, 4, 1), (4, 4, 2), (1, 8, 1), (1, 8, 2), (2, 8, 1), (2, 8, 2),
+               (4, 8, 1), (4, 8, 2), (1, 16, 2), (2, 16, 2)]]
+
+
+@pytest.fixture(autouse=True)
+def _default_variant():
+    hipabi.set_variant("gemv", -1)
+    yield
+    hipabi.set_variant("gemv", -1)
+
+
+def make_case(M, K, bs=64, seed=0, wscale=0.02):
+    rng = np.random.default_rng(seed)
+    w = (rng.standard_normal(M * K) * wscale).astype(np.float32)
+    packed, am = c_oracle.quantize(w, bs) if bs >= 2 else o.quantize_fp4(w, bs)
+    x = rng.standard_normal(K).astype(np.float32)
+    return packed, am, x
+
+
+def check(y: torch.Tensor, x_t: torch.Tensor, packed, am, M, K, bs, dtype, bias=None):
+    xv = x_t.float().cpu().numpy().astype(np.float64)
+    exact = c_oracle.gemv_f64(xv, packed, am, M, K, bs) if K % 2 == 0 else o.gemv_exact(xv, packed, am, M, K, bs)
+    wabs = np.abs(o.dequantize_f32(packed, am, bs, M * K).reshape(M, K).astype(np.float64))
+    scale = wabs @ np.abs(xv)
+    got = y.float().cpu().numpy().astype(np.float64)
+    if bias is not None:
+        # bias semantics are exact (T(T(sum) + bias)), checked separately; compare pre-bias here
+        raise AssertionError("use check() without bias")
+    tol = HALF_ULP[dtype] * 1.01 * np.abs(exact) + 1e-5 * scale + 1e-30
+    err = np.abs(got - exact)
+    worst = int(np.argmax(err - tol))
+    assert (err <= tol).all(), (worst, got[worst], exact[worst], err[worst], tol[worst])
+    return exact, err
+
+
+@pytest.mark.parametrize("tag", list("abc"))
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_golden_cases_and_reference_emulation(golden, tag, dtype):
+    M, K = (int(v) for v in golden[f"gemv{tag}_shape"])
+    packed, am, x = golden[f"gemv{tag}_packed"], golden[f"gemv{tag}_absmax"], golden[f"gemv{tag}_x"]
+    x_t = torch_values(x, dtype)
+    y = hipabi.gemv(x_t, to_dev(packed), to_dev(am), M, K, 64)
+    exact, err = check(y, x_t, packed, am, M, K, 64, dtype)
+    xv = x_t.float().cpu().numpy()
+    emu = o.gemv_reference_emulated(xv, packed, am, M, K, 64, NPDT[dtype]).astype(np.float64)
+    emu_err = np.abs(emu - o.gemv_exact(xv, packed, am, M, K, 64))
+    assert err.mean() <= emu_err.mean() * 1.05 + 1e-12, (err.mean(), emu_err.mean())
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("variant", VARIANTS16)
+def test_4096x4096_every_variant(dtype, variant):
+    M = K = 4096
+    packed, am, x = make_case(M, K, seed=1)
+    x_t = torch_values(x, dtype)
+    hipabi.set_variant("gemv", variant)
+    y = hipabi.gemv(x_t, to_dev(packed), to_dev(am), M, K, 64)
+    check(y, x_t, packed, am, M, K, 64, dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,K", [(14336, 4096), (4096, 14336), (1024, 4096), (2048, 768), (64, 2048), (66, 768), (5, 64), (1, 32),
+                                 (3, 8192), (257, 2112)])
+def test_model_shapes(dtype, M, K):
+    packed, am, x = make_case(M, K, seed=M + K)
+    x_t = torch_values(x, dtype)
+    y = hipabi.gemv(x_t, to_dev(packed), to_dev(am), M, K, 64)
+    check(y, x_t, packed, am, M, K, 64, dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,K,bs", [(37, 96, 32), (16, 80, 16), (9, 4096, 128), (12, 1024, 1024), (20, 256, 4096), (7, 66, 2),
+                                    (33, 2048, 32)])
+def test_blocksizes_and_generic_shapes(dtype, M, K, bs):
+    packed, am, x = make_case(M, K, bs=bs, seed=bs)
+    x_t = torch_values(x, dtype)
+    y = hipabi.gemv(x_t, to_dev(packed), to_dev(am), M, K, bs)
+    check(y, x_t, packed, am, M, K, bs, dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_fused_bias_equals_separate_add_bitwise(dtype):
+    M, K = 1000, 1024
+    packed, am, x = make_case(M, K, seed=3)
+    x_t = torch_values(x, dtype)
+    bias = torch_values(np.random.default_rng(4).standard_normal(M) * 0.1, dtype)
+    P, A = to_dev(packed), to_dev(am)
+    plain = hipabi.gemv(x_t, P, A, M, K, 64)
+    fused = hipabi.gemv(x_t, P, A, M, K, 64, bias=bias)
+    assert torch.equal(fused, plain + bias)  # the reference's `out += bias` (torch_bnb_fp4/__init__.py:608-613)
+
+
+def test_extreme_activations_and_signs():
+    # large-magnitude bf16 activations (beyond fp16 range) and a weight row of all -1.0 / +1.0 codes
+    M, K = 8, 2048
+    nib = np.where(np.arange(M * K) % 2 == 0, 3, 11).astype(np.uint8)  # +1, -1 alternating
+    packed = ((nib[0::2] << 4) | nib[1::2]).astype(np.uint8)
+    am = np.full(M * K // 64, 0.5, np.float32)
+    x = np.zeros(K, np.float32)
+    x[0::2] = 3.0e5
+    x[1::2] = 1.0e5
+    x_t = torch_values(x, torch.bfloat16)
+    y = hipabi.gemv(x_t, to_dev(packed), to_dev(am), M, K, 64)
+    xv = x_t.float().cpu().numpy().astype(np.float64)
+    want = 0.5 * (xv[0::2].sum() - xv[1::2].sum())
+    assert np.allclose(y.float().cpu().numpy(), want, rtol=2.0**-8)
+
+
+def test_torch_ext_gemv_shapes_and_errors():
+    import torch_bnb_fp4 as pkg
+
+    M, K = 192, 256
+    packed, am, x = make_case(M, K, seed=9)
+    B = to_dev(packed).view(-1, 1).t()  # what QuantData passes: [1, numel/2], still contiguous
+    absmax, code = to_dev(am), pkg.ext.code_table("tree").to(dev())
+    for dt in DTYPES:
+        x_t = torch_values(x, dt).view(1, K)
+        y2 = pkg.gemm_4bit_inference(x_t, B, absmax, code, 64, dt, torch.Size([M, K]))
+        y3 = pkg.gemm_4bit_inference(x_t.view(1, 1, K), B, absmax, code, 64, dt, [M, K])
+        assert y2.shape == (1, M) and y3.shape == (1, 1, M) and y2.dtype == dt
+        assert torch.equal(y2.view(-1), y3.view(-1))
+        assert torch.equal(y2.view(-1), hipabi.gemv(x_t.view(-1), to_dev(packed), absmax, M, K, 64))
+        yq = pkg.gemm_4bit_inference_qtype(x_t, B, absmax, code, 64, pkg.ScalarType.from_torch_dtype(dt).value, [M, K])
+        assert torch.equal(yq, y2)
+    with pytest.raises(RuntimeError, match="batch-1"):
+        pkg.gemm_4bit_inference(torch.zeros(2, K, device=dev(), dtype=torch.float16), B, absmax, code, 64, torch.float16, [M, K])
+    with pytest.raises(RuntimeError, match="dtype"):
+        pkg.gemm_4bit_inference(torch.zeros(1, K, device=dev(), dtype=torch.float16), B, absmax, code, 64, torch.bfloat16, [M, K])
+    with pytest.raises(RuntimeError, match="fp32 absmax"):
+        pkg.gemm_4bit_inference(torch.zeros(1, K, device=dev(), dtype=torch.float16), B, absmax.half(), code, 64, torch.float16, [M, K])

@@ -1,0 +1,159 @@
+"""Host-side logic of the torch_bnb_fp4 mirror package on CPU: enum, dispatch table of
+QuantData.forward (reference torch_bnb_fp4/__init__.py:560-618), bias handling, surgery helpers.
+The extension is replaced by tests/fake_ext.py (oracle-backed) so no GPU is needed."""
+import numpy as np
+import pytest
+import torch
+from torch import nn
+
+import torch_bnb_fp4 as pkg
+from fake_ext import FakeExt
+from oracle import fp4_oracle as o
+from torch_bnb_fp4 import functional as F_mod, quant_data as qd_mod
+
+
+@pytest.fixture()
+def fake(monkeypatch):
+    f = FakeExt(pkg.ext)
+    monkeypatch.setattr(F_mod, "ext", f)
+    monkeypatch.setattr(qd_mod, "ext", f)
+    return f
+
+
+def make_quant_data(M=128, K=256, bias=True, **kw):
+    rng = np.random.default_rng(0)
+    w = (rng.standard_normal(M * K) * 0.05).astype(np.float32)
+    packed, am = o.quantize_fp4(w, 64)
+    state = pkg.QuantState(torch.from_numpy(am), (M, K), torch.from_numpy(o.TREE_TABLE.copy()), 64)
+    lin = nn.Linear(K, M, bias=bias)
+    qd = pkg.QuantData(torch.from_numpy(packed).view(-1, 1), state, state.shape, original_lin=lin, **kw)
+    wq = torch.from_numpy(o.dequantize_f32(packed, am, 64, M * K)).view(M, K)
+    return qd, wq, lin
+
+
+def test_public_surface_matches_reference_names():
+    for name in ["ScalarType", "dequantize_fp4", "dequantize_fp4_codebook_invoke_qtype", "dequantize_fp4_codebook_invoke",
+                 "gemm_4bit_inference", "gemm_4bit_inference_qtype", "dequantize_fp4_qtype", "QuantData", "TorchFP4Linear",
+                 "swap_linear_with_bnb_linear", "check_if_name_contained_in_list", "todevice_if_necessary",
+                 "recursively_replace_with_fp4_linear"]:
+        assert hasattr(pkg, name), name
+    assert hasattr(pkg.TorchFP4Linear, "from_linear")
+    for op in ["dequantize_fp4", "dequantize_fp4_codebook", "gemv_fp4", "qlinear", "qlinear_bias", "qlinear_codebook",
+               "qlinear_codebook_bias", "ScalarType"]:
+        assert hasattr(pkg.ext, op), op  # reference csrc/torch_fp4.cpp:125-139
+
+
+def test_scalar_type_enum():
+    S = pkg.ScalarType
+    assert S.from_torch_dtype(torch.bfloat16) is S.bfloat16 and S.from_str("float16") is S.float16
+    assert S.float32.torch_dtype == torch.float32
+    assert int(S.float16.value) == 0 and int(S.float32.value) == 1 and int(S.bfloat16.value) == 2  # torch_fp4.cpp:22-26
+    with pytest.raises(ValueError):
+        S.from_torch_dtype(torch.int8)
+    with pytest.raises(ValueError):
+        S.from_str("int8")
+
+
+def test_ext_rejects_cpu_and_noncontiguous_tensors():
+    # CHECK_CUDA of the reference (csrc/torch_fp4.cpp:19,42-45) -> RuntimeError
+    with pytest.raises(RuntimeError, match="must be a CUDA tensor"):
+        pkg.dequantize_fp4(torch.zeros(32, 1, dtype=torch.uint8), torch.ones(1), 64, 8, 8)
+    with pytest.raises(RuntimeError, match="must be a CUDA tensor"):
+        pkg.gemm_4bit_inference(torch.zeros(1, 64), torch.zeros(1, 32, dtype=torch.uint8), torch.ones(1), torch.zeros(16), 64,
+                                torch.float32, [1, 64])
+    with pytest.raises(TypeError):
+        pkg.ext.dequantize_fp4(torch.zeros(32, dtype=torch.uint8), torch.ones(1), 64, 8, 8, 3)  # not a ScalarType
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+def test_dispatch_table(fake, dtype):
+    M, K = 128, 256
+    qd, wq, lin = make_quant_data(M, K)
+    tol = {torch.float32: 1e-5, torch.bfloat16: 6e-2, torch.float16: 1e-2}[dtype]
+    gen = torch.Generator().manual_seed(1)
+    cases = [((1, K), "gemv_fp4_bias", (1, M)), ((1, 1, K), "gemv_fp4_bias", (1, 1, M)), ((2, K), "dequantize_fp4_codebook", (2, M)),
+             ((1, 5, K), "dequantize_fp4_codebook", (1, 5, M)), ((1, 1, 1, K), "dequantize_fp4_codebook", (1, 1, 1, M))]
+    for shape, want_call, want_shape in cases:
+        fake.calls.clear()
+        x = torch.randn(*shape, generator=gen).to(dtype)
+        y = qd.forward(x)
+        assert fake.calls == [want_call], (shape, fake.calls)
+        assert o.expected_dispatch(shape, K, 64) == ("gemv" if "gemv" in want_call else "qlinear")
+        assert tuple(y.shape) == want_shape and y.dtype == dtype
+        ref = torch.nn.functional.linear(x.float(), wq, lin.bias.float())
+        assert (y.float() - ref).abs().max() <= tol * max(1.0, ref.abs().max().item())
+    assert qd.o_type == dtype and qd.bias.dtype == dtype  # bias cast on first call (:417-421)
+    # empty input -> empty output of the right shape, no op called (:580-589)
+    fake.calls.clear()
+    assert tuple(qd.forward(torch.empty(0, K, dtype=dtype)).shape) == (0, M) and fake.calls == []
+    assert tuple(qd.forward(torch.empty(1, 0, K, dtype=dtype)).shape) == (1, 0, M)
+
+
+def test_dispatch_non_multiple_of_blocksize_and_non_contiguous(fake):
+    # K % blocksize != 0 with a single token falls back to qlinear (:593-594); blocksize 32 makes 96 legal to quantise
+    rng = np.random.default_rng(2)
+    M, K = 16, 96
+    packed, am = o.quantize_fp4(rng.standard_normal(M * K).astype(np.float32), 32)
+    state = pkg.QuantState(torch.from_numpy(am), (M, K), torch.from_numpy(o.TREE_TABLE.copy()), 64)  # layer claims bs 64
+    qd = pkg.QuantData(torch.from_numpy(packed).view(-1, 1), state, state.shape, original_lin=nn.Linear(K, M, bias=False))
+    qd.forward(torch.randn(1, K))
+    assert fake.calls == ["dequantize_fp4_codebook"]
+    # non-contiguous single token -> made contiguous, then GEMV (:596-597)
+    qd2, wq, lin = make_quant_data(64, 128, bias=False)
+    fake.calls.clear()
+    x = torch.randn(128, 2)[:, 0].view(1, 128)  # stride 2
+    assert not x.is_contiguous()
+    y = qd2.forward(x)
+    assert fake.calls == ["gemv_fp4"] and torch.allclose(y, x @ wq.t(), atol=1e-4)
+
+
+def test_unfused_bias_and_tree_and_low_precision_paths(fake):
+    qd, wq, lin = make_quant_data(32, 128, fuse_bias=False, use_codebook_dequant=False)
+    x = torch.randn(1, 128)
+    y = qd.forward(x)
+    assert fake.calls == ["gemv_fp4"] and torch.allclose(y, x @ wq.t() + lin.bias, atol=1e-4)
+    fake.calls.clear()
+    qd.forward(torch.randn(3, 128))
+    assert fake.calls == ["dequantize_fp4"]  # tree dequant (:456-469)
+    for codebook, name in ((True, "qlinear_codebook_bias"), (False, "qlinear_bias")):
+        qd2, _, _ = make_quant_data(32, 128, allow_reduced_precision_linear=True, use_codebook_dequant=codebook)
+        fake.calls.clear()
+        qd2.forward(torch.randn(3, 128))
+        assert fake.calls == [name]
+    qd3, _, _ = make_quant_data(32, 128, bias=False, allow_reduced_precision_linear=True)
+    qd3.bias = None
+    fake.calls.clear()
+    qd3.forward(torch.randn(3, 128))
+    assert fake.calls == ["qlinear_codebook"]
+
+
+def test_surgery_helpers_cpu():
+    assert pkg.check_if_name_contained_in_list("model.lm_head", ["lm_head"])
+    assert not pkg.check_if_name_contained_in_list("proj", ["lm_head", "pooler"])
+    lin = nn.Linear(64, 32)
+    fp4 = pkg.swap_linear_with_bnb_linear(lin, dtype=torch.bfloat16)
+    assert isinstance(fp4, pkg.LinearFP4) and fp4.weight.quant_state is None
+    assert torch.equal(fp4.weight.data, lin.weight.data) and fp4.weight.data.data_ptr() != lin.weight.data.data_ptr()
+    assert torch.equal(fp4.bias.data, lin.bias.data) and not fp4.weight.requires_grad and not fp4.bias.requires_grad
+    x = torch.randn(3, 64)
+    assert torch.allclose(fp4(x), lin(x), atol=1e-6)  # dense until it reaches a GPU
+    assert fp4.to(torch.bfloat16).weight.dtype == torch.bfloat16 and isinstance(fp4.weight, pkg.Params4bit)
+    with pytest.raises(AssertionError, match="cuda"):
+        pkg.recursively_replace_with_fp4_linear(nn.Sequential(lin), device=torch.device("cpu"))
+    with pytest.raises(ValueError):
+        pkg.TorchFP4Linear(lin)  # not an FP4 layer
+    with pytest.raises(ValueError):
+        pkg.TorchFP4Linear(fp4)  # FP4 layer type, but not quantised / not on a GPU
+
+
+def test_product_package_never_imports_the_oracle():
+    import os
+    import re
+
+    root = os.path.dirname(os.path.abspath(pkg.__file__))
+    for dirpath, _, files in os.walk(os.path.dirname(root)):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, re.M), f
+                assert "fp4_oracle" not in text.replace("oracle/fp4_oracle.py", ""), f
