@@ -94,15 +94,23 @@ __device__ __forceinline__ float to_f32<FP4_DTYPE_F16>(uint16_t bits) {
     return float(__builtin_bit_cast(_Float16, bits));
 }
 
+// f32 -> T of a value that was just produced by an f32 multiply/add.  The optimisation barrier
+// keeps hipcc from folding "mul; cvt" into v_fma_mixlo_f16 (a*b + (+0.0)), which turns a -0.0
+// product into +0.0 - the FP4 code has a -0 entry (nibble 8), so that is a visible bit.
+__device__ __forceinline__ float opaque(float v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
 template <int DT>
 __device__ __forceinline__ uint16_t from_f32(float v);
 template <>
 __device__ __forceinline__ uint16_t from_f32<FP4_DTYPE_BF16>(float v) {
-    return __builtin_bit_cast(uint16_t, __bf16(v));
+    return __builtin_bit_cast(uint16_t, __bf16(opaque(v)));
 }
 template <>
 __device__ __forceinline__ uint16_t from_f32<FP4_DTYPE_F16>(float v) {
-    return __builtin_bit_cast(uint16_t, _Float16(v));
+    return __builtin_bit_cast(uint16_t, _Float16(opaque(v)));
 }
 
 }  // namespace fp4
