@@ -97,11 +97,26 @@ def time_replays(replay, reps, launches):
     return statistics.median(out), out
 
 
+def usable_cores() -> int:
+    """Host cores this process may really use: affinity mask, capped by the cgroup CPU quota if there is one."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, int(os.environ.get("FP4_BENCH_CPU_THREADS", "64"))))
+
+
 def cpu_baseline(budget_s=12.0):
     """Pure-torch dequant of the same 4096x4096 -> bf16 problem on the host cores."""
     from oracle import torch_cpu
 
-    ncores = os.cpu_count() or 1
+    ncores = usable_cores()
     torch.set_num_threads(ncores)
     g = torch.Generator().manual_seed(0)
     packed = torch.randint(0, 256, (M * K // 2,), dtype=torch.uint8, generator=g)
@@ -128,7 +143,8 @@ def cpu_baseline(budget_s=12.0):
         "cores": torch.get_num_threads(),
         "kind": "port",
         "sample": f"{len(times)} timed pure-torch CPU dequants of one 4096x4096 bs64 weight to bf16 (median {med * 1e3:.1f} ms; "
-                  f"os.cpu_count()={ncores}, torch threads={torch.get_num_threads()}); CPU dequant+GEMV once: {gemv_s * 1e3:.1f} ms",
+                  f"os.cpu_count()={os.cpu_count()}, usable={ncores}, torch threads={torch.get_num_threads()}); "
+                  f"CPU dequant+GEMV once: {gemv_s * 1e3:.1f} ms",
         "ms_per_matrix": round(med * 1e3, 3),
         "gemv_us_per_layer": round(gemv_s * 1e6, 1),
     }
@@ -298,7 +314,7 @@ def main():
                           "includes one kernel boundary per launch (rocprofv3 kernel durations: profiles/)",
             },
             "roofline_gemv": {
-                "bound": "hbm", "kernel": "gemv16_kernel<bf16> (fp4_hip_gemv)", "achieved": round(gv_gbps_gpu, 1),
+                "bound": "hbm", "kernel": "gemv16_regx_kernel<bf16> (fp4_hip_gemv)", "achieved": round(gv_gbps_gpu, 1),
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(gv_gbps_gpu / HBM_PEAK_GBPS, 4), "traffic": None,
                 "bytes_per_launch": gv_b, "avg_launch_us": round(gv_us, 3),
             },

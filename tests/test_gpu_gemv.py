@@ -23,7 +23,7 @@ DTYPES = [torch.bfloat16, torch.float16, torch.float32]
 HALF_ULP = {torch.bfloat16: 2.0**-8, torch.float16: 2.0**-11, torch.float32: 0.0}
 VARIANTS16 = [r | (w << 8) | (u << 16) for (r, w, u) in
               [(1, 4, 1), (1, 4, 2), (2, 4, 1), (2, 4, 2), (4, 4, 1), (4, 4, 2), (1, 8, 1), (1, 8, 2), (2, 8, 1), (2, 8, 2),
-               (4, 8, 1), (4, 8, 2), (1, 16, 2), (2, 16, 2)]]
+               (4, 8, 1), (4, 8, 2), (1, 16, 2), (2, 16, 2)]] + [(1 << 24) | it for it in (1, 2, 4, 8)]  # + register-x family
 
 
 @pytest.fixture(autouse=True)
@@ -88,6 +88,20 @@ def test_4096x4096_every_variant(dtype, variant):
 def test_model_shapes(dtype, M, K):
     packed, am, x = make_case(M, K, seed=M + K)
     x_t = torch_values(x, dtype)
+    y = hipabi.gemv(x_t, to_dev(packed), to_dev(am), M, K, 64)
+    check(y, x_t, packed, am, M, K, 64, dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("iters", [1, 2, 4, 8])
+@pytest.mark.parametrize("M,K", [(14336, 4096), (4096, 14336), (1024, 4096), (2048, 768), (64, 2048), (66, 768), (5, 64), (1, 32),
+                                 (3, 8192), (257, 2112), (100, 16384), (7, 32768), (33, 1024), (19, 2048)])
+def test_register_x_geometry_all_band_splits(dtype, iters, M, K):
+    """The second GEMV geometry (x in registers, K split across waves): every KSPLIT x G instantiation,
+    ragged M, idle lanes, and the K > 16384 fall-back to the LDS geometry."""
+    packed, am, x = make_case(M, K, seed=M * 7 + K)
+    x_t = torch_values(x, dtype)
+    hipabi.set_variant("gemv", (1 << 24) | iters)
     y = hipabi.gemv(x_t, to_dev(packed), to_dev(am), M, K, 64)
     check(y, x_t, packed, am, M, K, 64, dtype)
 

@@ -1,0 +1,206 @@
+// Standalone GEMV experiment (no torch): every geometry of fp4_hip_gemv through the C ABI, next to
+// "floor" kernels that only stream the same bytes, HBM-cold (R rotating weights) and cache-hot.
+// Build on the GPU box:
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Iinclude -Itorch-bnb-fp4_amd/csrc \
+//         tools/exp_gemv.hip torch-bnb-fp4_amd/csrc/{capi,dequant_fp4,gemv_fp4,quantize_fp4}.hip -o /tmp/exp_gemv
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "torch_bnb_fp4_hip.h"
+
+#define CK(x)                                                                             \
+    do {                                                                                  \
+        hipError_t e_ = (x);                                                              \
+        if (e_ != hipSuccess) {                                                           \
+            printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); \
+            exit(1);                                                                      \
+        }                                                                                 \
+    } while (0)
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// floor: every lane loads LOADS x 16 B of the packed stream (all issued up front), xors them, one dword store per wave
+template <int LOADS, int THREADS, bool NT>
+__global__ __launch_bounds__(THREADS) void stream_floor(const u32x4 *__restrict__ W, const float *__restrict__ absmax,
+                                                        uint32_t *__restrict__ out, int nchunks) {
+    const int64_t base = (int64_t(blockIdx.x) * THREADS + threadIdx.x);
+    const int64_t stride = int64_t(gridDim.x) * THREADS;
+    u32x4 v[LOADS];
+    float a[LOADS];
+#pragma unroll
+    for (int j = 0; j < LOADS; ++j) {
+        const int64_t c = base + j * stride;
+        if (c < nchunks) {
+            v[j] = NT ? __builtin_nontemporal_load(W + c) : W[c];
+            a[j] = absmax[c >> 1];
+        } else {
+            v[j] = u32x4{0, 0, 0, 0};
+            a[j] = 0.f;
+        }
+    }
+    uint32_t acc = 0;
+#pragma unroll
+    for (int j = 0; j < LOADS; ++j) acc ^= v[j].x ^ v[j].y ^ v[j].z ^ v[j].w ^ __builtin_bit_cast(uint32_t, a[j]);
+    for (int m = 32; m >= 1; m >>= 1) acc ^= __shfl_xor(acc, m);
+    if ((threadIdx.x & 63) == 0) out[(blockIdx.x * THREADS + threadIdx.x) >> 6] = acc;
+}
+
+__global__ void empty_kernel(uint32_t *out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0 && out == nullptr) out[0] = 1;
+}
+
+static float bf16_to_f(uint16_t b) {
+    uint32_t u = uint32_t(b) << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+static uint16_t f_to_bf16(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+
+struct Timer {
+    hipStream_t s;
+    hipEvent_t e0, e1;
+    template <typename F>
+    void run(const char *name, int launches, double bytes, F &&record) {
+        hipGraph_t g;
+        hipGraphExec_t ge;
+        CK(hipStreamBeginCapture(s, hipStreamCaptureModeGlobal));
+        record();
+        CK(hipStreamEndCapture(s, &g));
+        CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+        for (int w = 0; w < 3; ++w) CK(hipGraphLaunch(ge, s));
+        CK(hipStreamSynchronize(s));
+        std::vector<float> t;
+        for (int rep = 0; rep < 9; ++rep) {
+            CK(hipEventRecord(e0, s));
+            CK(hipGraphLaunch(ge, s));
+            CK(hipEventRecord(e1, s));
+            CK(hipEventSynchronize(e1));
+            float ms;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            t.push_back(ms * 1e3f / launches);
+        }
+        std::sort(t.begin(), t.end());
+        printf("%-44s med %7.3f us  min %7.3f us  -> %7.1f GB/s\n", name, t[t.size() / 2], t[0], bytes / t[t.size() / 2] / 1e3);
+        fflush(stdout);
+        CK(hipGraphExecDestroy(ge));
+        CK(hipGraphDestroy(g));
+    }
+};
+
+int main(int argc, char **argv) {
+    const int M = argc > 1 ? atoi(argv[1]) : 4096, K = argc > 2 ? atoi(argv[2]) : 4096;
+    const int64_t n = int64_t(M) * K;
+    const int R = (int)std::max<int64_t>(8, std::min<int64_t>(64, (int64_t)(700e6 / (n * 0.5625))));
+    std::vector<uint8_t> hp(n / 2);
+    std::vector<float> ha(n / 64);
+    std::vector<uint16_t> hx(K);
+    srand(3);
+    for (auto &b : hp) b = (uint8_t)rand();
+    for (auto &f : ha) f = 0.01f + 0.1f * (rand() / (float)RAND_MAX);
+    for (auto &v : hx) v = f_to_bf16((rand() / (float)RAND_MAX) * 2.f - 1.f);
+    std::vector<uint8_t *> packed(R);
+    std::vector<float *> absmax(R);
+    for (int i = 0; i < R; ++i) {
+        CK(hipMalloc(&packed[i], n / 2));
+        CK(hipMalloc(&absmax[i], n / 64 * 4));
+        CK(hipMemcpy(packed[i], hp.data(), n / 2, hipMemcpyHostToDevice));
+        CK(hipMemcpy(absmax[i], ha.data(), n / 64 * 4, hipMemcpyHostToDevice));
+    }
+    uint16_t *x, *y;
+    uint32_t *scratch;
+    CK(hipMalloc(&x, K * 2));
+    CK(hipMalloc(&y, M * 2));
+    CK(hipMalloc(&scratch, 1 << 20));
+    CK(hipMemcpy(x, hx.data(), K * 2, hipMemcpyHostToDevice));
+    Timer T;
+    CK(hipStreamCreate(&T.s));
+    CK(hipEventCreate(&T.e0));
+    CK(hipEventCreate(&T.e1));
+    const double bytes = n / 2.0 + n / 64.0 * 4 + (K + M) * 2.0;
+    const int reps = 4;
+    printf("M=%d K=%d R=%d  algorithmic bytes %.0f\n", M, K, R, bytes);
+
+    T.run("empty kernel chain (launch boundary)", 256, 0.0, [&] {
+        for (int i = 0; i < 256; ++i) hipLaunchKernelGGL(empty_kernel, dim3(256), dim3(256), 0, T.s, scratch);
+    });
+    const int nchunks = (int)(n / 32);
+#define FLOOR(L, TH, NT, COLD)                                                                                        \
+    T.run("floor L" #L " T" #TH " nt=" #NT " cold=" #COLD, R * reps, bytes, [&] {                                     \
+        for (int i = 0; i < R * reps; ++i) {                                                                          \
+            const int w = COLD ? i % R : 0;                                                                           \
+            const int blocks = (nchunks + L * TH - 1) / (L * TH);                                                     \
+            hipLaunchKernelGGL((stream_floor<L, TH, NT>), dim3(blocks), dim3(TH), 0, T.s, (const u32x4 *)packed[w], \
+                               absmax[w], scratch, nchunks);                                                          \
+        }                                                                                                             \
+    });
+    FLOOR(1, 256, false, true) FLOOR(2, 256, false, true) FLOOR(4, 256, false, true) FLOOR(8, 256, false, true)
+    FLOOR(2, 256, true, true) FLOOR(4, 256, true, true) FLOOR(2, 512, true, true) FLOOR(4, 512, true, true) FLOOR(2, 1024, true, true)
+    FLOOR(2, 256, true, false) FLOOR(4, 256, true, false)
+
+    // CPU reference for a handful of rows
+    auto ref_row = [&](int r) {
+        static const float mag[8] = {0.f, 0.0052083330f, 0.6666667f, 1.f, 0.333333f, 0.5f, 0.1666667f, 0.25f};
+        double acc = 0;
+        for (int k = 0; k < K; ++k) {
+            const int64_t e = int64_t(r) * K + k;
+            const uint8_t b = hp[e >> 1];
+            const int nib = (e & 1) ? (b & 15) : (b >> 4);
+            const float w = (nib & 8 ? -mag[nib & 7] : mag[nib & 7]) * ha[e / 64];
+            acc += (double)w * bf16_to_f(hx[k]);
+        }
+        return acc;
+    };
+    const int check_rows[6] = {0, 1, 7, M / 2 + 3, M - 2, M - 1};
+    double refs[6];
+    for (int i = 0; i < 6; ++i) refs[i] = ref_row(check_rows[i]);
+
+    std::vector<std::pair<const char *, int>> variants = {
+        {"lds r1 w4 u2", 1 | (4 << 8) | (2 << 16)},   {"lds r1 w8 u2", 1 | (8 << 8) | (2 << 16)},
+        {"lds r1 w16 u2", 1 | (16 << 8) | (2 << 16)}, {"lds r2 w4 u2", 2 | (4 << 8) | (2 << 16)},
+        {"regx it1", (1 << 24) | 1},                  {"regx it2", (1 << 24) | 2},
+        {"regx it4", (1 << 24) | 4},                  {"regx it8", (1 << 24) | 8},
+        {"default heuristic", -1},
+    };
+    for (auto &v : variants) {
+        if (fp4_hip_set_variant("gemv", v.second)) {
+            printf("set_variant failed\n");
+            return 1;
+        }
+        CK(hipMemset(y, 0xFF, M * 2));
+        int rc = fp4_hip_gemv(x, packed[0], absmax[0], nullptr, y, M, K, 64, FP4_DTYPE_BF16, T.s);
+        CK(hipStreamSynchronize(T.s));
+        if (rc) {
+            printf("%s: rc=%d %s\n", v.first, rc, fp4_hip_last_error());
+            continue;
+        }
+        std::vector<uint16_t> hy(M);
+        CK(hipMemcpy(hy.data(), y, M * 2, hipMemcpyDeviceToHost));
+        double maxrel = 0;
+        for (int i = 0; i < 6; ++i) {
+            const double got = bf16_to_f(hy[check_rows[i]]);
+            maxrel = std::max(maxrel, std::fabs(got - refs[i]) / (std::fabs(refs[i]) + 1e-3));
+        }
+        char name[96];
+        snprintf(name, sizeof name, "gemv %s cold (maxrel %.1e)", v.first, maxrel);
+        T.run(name, R * reps, bytes, [&] {
+            for (int i = 0; i < R * reps; ++i) fp4_hip_gemv(x, packed[i % R], absmax[i % R], nullptr, y, M, K, 64, FP4_DTYPE_BF16, T.s);
+        });
+        snprintf(name, sizeof name, "gemv %s hot", v.first);
+        T.run(name, R * reps, bytes, [&] {
+            for (int i = 0; i < R * reps; ++i) fp4_hip_gemv(x, packed[0], absmax[0], nullptr, y, M, K, 64, FP4_DTYPE_BF16, T.s);
+        });
+    }
+    return 0;
+}

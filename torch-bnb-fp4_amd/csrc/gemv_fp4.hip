@@ -109,6 +109,9 @@ struct WTrip {  // one trip of a wave: UNROLL chunks x ROWS rows of packed weigh
     float am[UNROLL][ROWS];
 };
 
+// Branch-free on purpose: a load inside a divergent `if` makes hipcc drain the whole queue (vmcnt(0)) at the
+// join, which would serialise "all weights arrived" -> "first FMA".  Out-of-range chunks are clamped to the
+// last valid one and neutralised through a zero scale instead.
 template <int ROWS, int UNROLL>
 __device__ __forceinline__ void issue_trip(WTrip<ROWS, UNROLL> &t, const u32x4 *__restrict__ Wv,
                                            const float *__restrict__ absmax, const int (&rows)[ROWS], int c0, int C,
@@ -116,16 +119,13 @@ __device__ __forceinline__ void issue_trip(WTrip<ROWS, UNROLL> &t, const u32x4 *
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
         const int c = c0 + 64 * u;
+        const int cc = c < C ? c : C - 1;
 #pragma unroll
         for (int r = 0; r < ROWS; ++r) {
-            const int64_t chunk = int64_t(rows[r]) * C + c;
-            if (c < C) {
-                t.wq[u][r] = __builtin_nontemporal_load(Wv + chunk);
-                t.am[u][r] = absmax[(chunk << 5) >> bs_shift];
-            } else {
-                t.wq[u][r] = u32x4{0u, 0u, 0u, 0u};
-                t.am[u][r] = 0.0f;
-            }
+            const int64_t chunk = int64_t(rows[r]) * C + cc;
+            t.wq[u][r] = __builtin_nontemporal_load(Wv + chunk);
+            const float a = absmax[(chunk << 5) >> bs_shift];
+            t.am[u][r] = c < C ? a : 0.0f;
         }
     }
 }
@@ -136,24 +136,23 @@ __device__ __forceinline__ void consume_trip(const WTrip<ROWS, UNROLL> &t, const
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
         const int c = c0 + 64 * u;
-        if (c < C) {
-            u32x4 xd[4];
+        const int cc = c < C ? c : C - 1;  // clamped chunks carry a zero scale
+        u32x4 xd[4];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) xd[g] = s_x4[g * C + c];
+        for (int g = 0; g < 4; ++g) xd[g] = s_x4[g * C + cc];
 #pragma unroll
-            for (int r = 0; r < ROWS; ++r) {
-                float s[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int r = 0; r < ROWS; ++r) {
+            float s[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    uint32_t P[4];
-                    decode8<DT>(t.wq[u][r][g], P);
-                    s[g] = dot2<DT>(P[0], xd[g].x, s[g]);
-                    s[g] = dot2<DT>(P[1], xd[g].y, s[g]);
-                    s[g] = dot2<DT>(P[2], xd[g].z, s[g]);
-                    s[g] = dot2<DT>(P[3], xd[g].w, s[g]);
-                }
-                acc[r] = __builtin_fmaf((s[0] + s[1]) + (s[2] + s[3]), t.am[u][r], acc[r]);
+            for (int g = 0; g < 4; ++g) {
+                uint32_t P[4];
+                decode8<DT>(t.wq[u][r][g], P);
+                s[g] = dot2<DT>(P[0], xd[g].x, s[g]);
+                s[g] = dot2<DT>(P[1], xd[g].y, s[g]);
+                s[g] = dot2<DT>(P[2], xd[g].z, s[g]);
+                s[g] = dot2<DT>(P[3], xd[g].w, s[g]);
             }
+            acc[r] = __builtin_fmaf((s[0] + s[1]) + (s[2] + s[3]), t.am[u][r], acc[r]);
         }
     }
 }
@@ -179,19 +178,33 @@ __global__ __launch_bounds__(WAVES * 64) void gemv16_kernel(const uint16_t *__re
     for (int r = 0; r < ROWS; ++r) rows[r] = (row0 + r < M) ? row0 + r : M - 1;  // clamped rows are computed, not stored
     const u32x4 *Wv = reinterpret_cast<const u32x4 *>(W);
 
-    // the weight stream of the first trip goes out before anything else: it is the HBM-latency-bound part
+    // Order matters: vector-memory results return in issue order (vmcnt), so the (L2-resident) x pieces are
+    // requested FIRST and the HBM weight stream of the first trip right behind them; the LDS staging of x
+    // then only waits for the x pieces while the weights are still in flight.
+    constexpr int kXPre = 2;  // x pieces per thread requested ahead of the weights (covers K <= 4096 * WAVES / 4)
+    u32x4 xpre[kXPre];
+#pragma unroll
+    for (int i = 0; i < kXPre; ++i) {
+        const int p = tid + i * WAVES * 64;
+        xpre[i] = reinterpret_cast<const u32x4 *>(x)[p < 4 * C ? p : 4 * C - 1];
+    }
     WTrip<ROWS, UNROLL> ta, tb;
     issue_trip<ROWS, UNROLL>(ta, Wv, absmax, rows, lane, C, bs_shift);
 
-    for (int p = tid; p < 4 * C; p += WAVES * 64) {
-        const u32x4 w = reinterpret_cast<const u32x4 *>(x)[p];
+    auto stage = [&](int p, const u32x4 w) {
         u32x4 d;
         d.x = perm(w.y, w.x, 0x05040100u);  // (x0,x2)
         d.y = perm(w.w, w.z, 0x05040100u);  // (x4,x6)
         d.z = perm(w.y, w.x, 0x07060302u);  // (x1,x3)
         d.w = perm(w.w, w.z, 0x07060302u);  // (x5,x7)
         s_x4[(p & 3) * C + (p >> 2)] = d;
+    };
+#pragma unroll
+    for (int i = 0; i < kXPre; ++i) {
+        const int p = tid + i * WAVES * 64;
+        if (p < 4 * C) stage(p, xpre[i]);
     }
+    for (int p = tid + kXPre * WAVES * 64; p < 4 * C; p += WAVES * 64) stage(p, reinterpret_cast<const u32x4 *>(x)[p]);
     __syncthreads();
 
     float acc[ROWS];
@@ -212,6 +225,125 @@ __global__ __launch_bounds__(WAVES * 64) void gemv16_kernel(const uint16_t *__re
     for (int r = 0; r < ROWS; ++r) {
         const float total = wave_sum(acc[r]) * (1.0f / 12.0f);
         if (lane == 0 && row0 + r < M) store_row<DT>(out, bias, row0 + r, total);
+    }
+}
+
+// ---- 16-bit activations, second geometry: x in registers, K split across the waves of a workgroup ----
+// For decode shapes the LDS staging of x (K*2 bytes per workgroup, a barrier before the first FMA, and
+// as much L2->LDS traffic as the weight stream itself at 4 rows per workgroup) is the critical path,
+// not HBM.  Here a lane owns the SAME K-chunks for every row its workgroup handles, so its slice of x is
+// loaded from L2 once into VGPRs and never touches LDS:
+//   * 4 waves; wave w = (kw, rw): kw in [0,KSPLIT) picks a 32-chunk column band, rw a row-pair group;
+//     the two 32-lane halves of a wave work on two different rows (one 512-byte span of each per load);
+//   * lane (kw, l&31) owns chunks  g*32*KSPLIT + kw*32 + (l&31),  g < G   (G*16 VGPRs of permuted x);
+//   * a workgroup handles ITERS row-pairs per row group; every weight load of the workgroup is issued
+//     before the first dot2; per (row, band) partial sums meet in LDS (KSPLIT floats per row), one
+//     barrier at the very end; with KSPLIT == 1 nothing is shared at all.
+template <int DT, int KSPLIT, int G, int ITERS>
+__global__ __launch_bounds__(256) void gemv16_regx_kernel(const uint16_t *__restrict__ x, const uint8_t *__restrict__ W,
+                                                          const float *__restrict__ absmax,
+                                                          const uint16_t *__restrict__ bias, uint16_t *__restrict__ out,
+                                                          int M, int K, int bs_shift) {
+    constexpr int RG = 4 / KSPLIT;               // row-pair groups per workgroup
+    constexpr int kRowsPerBlock = 2 * RG * ITERS;
+    __shared__ float s_part[kRowsPerBlock][KSPLIT];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int kw = wave % KSPLIT, rw = wave / KSPLIT;
+    const int half = lane >> 5, l32 = lane & 31;
+    const int C = K >> 5;
+    const int row_base = blockIdx.x * kRowsPerBlock;
+    const u32x4 *Wv = reinterpret_cast<const u32x4 *>(W);
+
+    // Everything below is branch-free (see issue_trip): dead lanes / rows are clamped and get a zero scale.
+    int cidx[G];
+    bool live[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const int c = g * (32 * KSPLIT) + kw * 32 + l32;
+        live[g] = c < C;
+        cidx[g] = live[g] ? c : C - 1;
+    }
+    // 1. this lane's slice of x first: results return in issue order, and x (L2-resident, shared by every
+    //    workgroup) must not queue behind the HBM weight stream
+    u32x4 xraw[G][4];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) xraw[g][q] = reinterpret_cast<const u32x4 *>(x)[cidx[g] * 4 + q];
+    }
+    // 2. the whole weight stream of this lane, issued up front
+    u32x4 wq[ITERS][G];
+    float am[ITERS][G];
+    int rowi[ITERS];
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int local = 2 * (it * RG + rw) + half;
+        const int row = row_base + local;
+        rowi[it] = local;
+        const int rclamp = row < M ? row : M - 1;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int64_t chunk = int64_t(rclamp) * C + cidx[g];
+            wq[it][g] = __builtin_nontemporal_load(Wv + chunk);
+            const float a = absmax[(chunk << 5) >> bs_shift];
+            am[it][g] = live[g] ? a : 0.0f;
+        }
+    }
+    // permute x to decode8's pairing: (x0,x2) (x4,x6) (x1,x3) (x5,x7) per group of 8
+    u32x4 xd[G][4];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const u32x4 w = xraw[g][q];
+            xd[g][q].x = perm(w.y, w.x, 0x05040100u);
+            xd[g][q].y = perm(w.w, w.z, 0x05040100u);
+            xd[g][q].z = perm(w.y, w.x, 0x07060302u);
+            xd[g][q].w = perm(w.w, w.z, 0x07060302u);
+        }
+    }
+    // 3. decode + dot, one row per half-wave per iteration
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        float p = 0.0f;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            float s[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                uint32_t P[4];
+                decode8<DT>(wq[it][g][q], P);
+                s[q] = dot2<DT>(P[0], xd[g][q].x, s[q]);
+                s[q] = dot2<DT>(P[1], xd[g][q].y, s[q]);
+                s[q] = dot2<DT>(P[2], xd[g][q].z, s[q]);
+                s[q] = dot2<DT>(P[3], xd[g][q].w, s[q]);
+            }
+            p = __builtin_fmaf((s[0] + s[1]) + (s[2] + s[3]), am[it][g], p);
+        }
+        // sum over the 32 lanes of this half-wave
+        p = dpp_add<0x128>(p);
+        p = dpp_add<0x124>(p);
+        p = dpp_add<0x122>(p);
+        p = dpp_add<0x121>(p);
+        p += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, p), 0x401F));
+        if constexpr (KSPLIT == 1) {
+            const int row = row_base + rowi[it];
+            if (l32 == 0 && row < M) store_row<DT>(out, bias, row, p * (1.0f / 12.0f));
+        } else {
+            if (l32 == 0) s_part[rowi[it]][kw] = p;
+        }
+    }
+    if constexpr (KSPLIT > 1) {
+        __syncthreads();
+        if (tid < kRowsPerBlock) {
+            float t = 0.0f;
+#pragma unroll
+            for (int k = 0; k < KSPLIT; ++k) t += s_part[tid][k];
+            const int row = row_base + tid;
+            if (row < M) store_row<DT>(out, bias, row, t * (1.0f / 12.0f));
+        }
     }
 }
 
@@ -316,7 +448,7 @@ __global__ __launch_bounds__(256) void gemv_generic_kernel(const void *__restric
     }
 }
 
-int g_gemv_variant = -1;  // ROWS | WAVES << 8 | UNROLL << 16, or -1 = heuristic
+int g_gemv_variant = -1;  // LDS geometry: ROWS | WAVES << 8 | UNROLL << 16; register-x geometry: 1 << 24 | ITERS; -1 = heuristic
 
 constexpr int kMaxLdsBytes = 160 * 1024 - 256;
 
@@ -362,13 +494,65 @@ int dispatch16(int variant, const void *x, const uint8_t *W, const float *absmax
     }
 }
 
+constexpr int kRegxFlag = 1 << 24;
+
+template <int DT, int KSPLIT, int G, int ITERS>
+int launch_regx(const void *x, const uint8_t *W, const float *absmax, const void *bias, void *out, int M, int K, int bs_shift,
+                hipStream_t stream) {
+    constexpr int rows_per_block = 2 * (4 / KSPLIT) * ITERS;
+    const unsigned blocks = (unsigned)((M + rows_per_block - 1) / rows_per_block);
+    hipLaunchKernelGGL((gemv16_regx_kernel<DT, KSPLIT, G, ITERS>), dim3(blocks), dim3(256), 0, stream,
+                       reinterpret_cast<const uint16_t *>(x), W, absmax, reinterpret_cast<const uint16_t *>(bias),
+                       reinterpret_cast<uint16_t *>(out), M, K, bs_shift);
+    return FP4_OK;
+}
+
+// K decides the band split and the x-slice depth; ITERS (row pairs per group) is the tunable.
+template <int DT>
+int dispatch_regx(int iters, const void *x, const uint8_t *W, const float *absmax, const void *bias, void *out, int M, int K,
+                  int bs_shift, hipStream_t stream) {
+    const int C = K >> 5;
+#define FP4_RX(KS, GG, IT) return launch_regx<DT, KS, GG, IT>(x, W, absmax, bias, out, M, K, bs_shift, stream)
+#define FP4_RX_IT(KS, GG)          \
+    switch (iters) {               \
+        case 1: FP4_RX(KS, GG, 1); \
+        case 2: FP4_RX(KS, GG, 2); \
+        case 4: FP4_RX(KS, GG, 4); \
+        case 8: FP4_RX(KS, GG, 8); \
+        default: break;            \
+    }
+    if (C <= 32) {
+        FP4_RX_IT(1, 1)
+    } else if (C <= 64) {
+        FP4_RX_IT(2, 1)
+    } else if (C <= 128) {
+        FP4_RX_IT(4, 1)
+    } else if (C <= 256) {
+        if (iters > 4) iters = 4;
+        FP4_RX_IT(4, 2)
+    } else if (C <= 512) {
+        if (iters > 2) iters = 2;
+        FP4_RX_IT(4, 4)
+    } else {
+        return -1;  // K > 16384: the x slice no longer fits the register budget; use the LDS geometry
+    }
+#undef FP4_RX_IT
+#undef FP4_RX
+    set_error("fp4_hip_gemv: unknown regx iteration count %d", iters);
+    return FP4_ERR_INVALID_ARGUMENT;
+}
+
 int default_variant16(int M, int K) {
-    (void)K;
-    // one wave per row, 4 waves per workgroup; fold rows into a wave only when M alone
-    // already gives every CU several workgroups
-    int rows = 1;
-    if (M >= 8192) rows = 2;
-    return rows | (4 << 8) | (2 << 16);
+    // Measured on MI355X (profiles/r01_*): the register-x geometry wins at every decode shape it covers;
+    // rows per workgroup grow with M so that the grid stays at >= ~1024 workgroups (one resident round at
+    // 4096 rows, ~2 at 14336).  K > 16384 falls back to the LDS geometry inside dispatch.
+    const int C = K >> 5;
+    const int ksplit = C <= 32 ? 1 : (C <= 64 ? 2 : 4);
+    const int rows_per_iter = 2 * (4 / ksplit);
+    const int max_iters = C <= 128 ? 4 : (C <= 256 ? 4 : 2);
+    int iters = 1;
+    while (iters * 2 <= max_iters && M / (rows_per_iter * iters * 2) >= 1024) iters *= 2;
+    return kRegxFlag | iters;
 }
 
 template <int DT>
@@ -416,10 +600,19 @@ extern "C" int fp4_hip_gemv(const void *x, const uint8_t *packed, const float *a
                       size_t(K) * esz <= size_t(kMaxLdsBytes);
     int rc = FP4_OK;
     if (fast && dtype != FP4_DTYPE_F32) {
-        const int variant = g_gemv_variant >= 0 ? g_gemv_variant : default_variant16((int)M, (int)K);
-        rc = dtype == FP4_DTYPE_F16
-                 ? dispatch16<FP4_DTYPE_F16>(variant, x, packed, absmax, bias, out, (int)M, (int)K, bs_shift, s)
-                 : dispatch16<FP4_DTYPE_BF16>(variant, x, packed, absmax, bias, out, (int)M, (int)K, bs_shift, s);
+        int variant = g_gemv_variant >= 0 ? g_gemv_variant : default_variant16((int)M, (int)K);
+        rc = -1;
+        if (variant & kRegxFlag) {
+            const int iters = variant & 0xFF;
+            rc = dtype == FP4_DTYPE_F16
+                     ? dispatch_regx<FP4_DTYPE_F16>(iters, x, packed, absmax, bias, out, (int)M, (int)K, bs_shift, s)
+                     : dispatch_regx<FP4_DTYPE_BF16>(iters, x, packed, absmax, bias, out, (int)M, (int)K, bs_shift, s);
+            if (rc == -1) variant = 1 | (8 << 8) | (2 << 16);  // K too large for register-resident x
+        }
+        if (rc == -1)
+            rc = dtype == FP4_DTYPE_F16
+                     ? dispatch16<FP4_DTYPE_F16>(variant, x, packed, absmax, bias, out, (int)M, (int)K, bs_shift, s)
+                     : dispatch16<FP4_DTYPE_BF16>(variant, x, packed, absmax, bias, out, (int)M, (int)K, bs_shift, s);
     } else if (fast) {
         auto kern = gemv32_kernel<1, 4>;
         const size_t lds = size_t(K) * 4;
