@@ -97,6 +97,21 @@ def time_replays(replay, reps, launches):
     return statistics.median(out), out
 
 
+def committed_traffic(prefix: str):
+    """Per-launch HBM bytes of a kernel from the committed PMC profile (profiles/*traffic.json, produced by
+    tools/pmc_traffic.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this very script)."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "*traffic.json")))
+    if not files:
+        return None, None
+    data = json.load(open(files[-1]))
+    for name, rec in data.items():
+        if name.startswith(prefix):
+            return rec["traffic_bytes"], f"{os.path.relpath(files[-1], REPO)}:{name}"
+    return None, None
+
+
 def usable_cores() -> int:
     """Host cores this process may really use: affinity mask, capped by the cgroup CPU quota if there is one."""
     try:
@@ -319,6 +334,10 @@ def main():
                 "bytes_per_launch": gv_b, "avg_launch_us": round(gv_us, 3),
             },
         }
+        for key, prefix in (("roofline", "dequant_tiles_kernel<2,"), ("roofline_gemv", "gemv16_regx_kernel<2,")):
+            traffic, src = committed_traffic(prefix)
+            line[key]["traffic"] = traffic
+            line[key]["traffic_source"] = src
         line.update(extra)
         if "dequant_plus_hipblaslt_gemv_us" in extra:
             line["fused_gemv_speedup_vs_dequant_hipblaslt"] = round(extra["dequant_plus_hipblaslt_gemv_us"] / gv_us, 2)
