@@ -82,6 +82,15 @@ FP4_HIP_API int fp4_hip_gemv(const void *x, const uint8_t *packed, const float *
                  int64_t K, int blocksize, int dtype, void *stream);
 
 /*
+ * K-split (row-parallel) building block: the same GEMV, but the f32 accumulator is written as is
+ * (out_f32 : float[M], no bias, no rounding to T), so that the partial sums of the column shards
+ * of one weight can be added across GPUs (RCCL all-reduce) before the single final rounding.
+ * Not in the reference (it has no multi-GPU path); x is T[K] of x_dtype.
+ */
+FP4_HIP_API int fp4_hip_gemv_partial(const void *x, const uint8_t *packed, const float *absmax, float *out_f32, int64_t M,
+                                     int64_t K, int blocksize, int x_dtype, void *stream);
+
+/*
  * Blockwise FP4 quantiser (the producer side; bitsandbytes' quantize_fp4 as called at
  * torch_bnb_fp4/__init__.py:775 and inside Params4bit.cuda(), :861):
  * per block of `blocksize` elements absmax = max|w|, code = nearest FP4 magnitude of

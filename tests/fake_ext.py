@@ -54,6 +54,13 @@ class FakeExt:
         self.calls.append("gemv_fp4_bias")
         return self._gemv(A, B, absmax, blocksize, dtype, Bshape, bias)
 
+    def gemv_fp4_partial(self, A, B, absmax, blocksize, Bshape):
+        self.calls.append("gemv_fp4_partial")
+        M, K = Bshape
+        assert A.is_contiguous() and A.numel() == K
+        y = o.gemv_exact(A.float().numpy().reshape(-1), B.numpy().reshape(-1), absmax.numpy(), M, K, blocksize)
+        return torch.from_numpy(y).float().view(1, M)
+
     def _qlinear(self, name, A_in, A, absmax, M, N, blocksize, table, bias=None):
         self.calls.append(name)
         w = self._deq(A, absmax, M, N, blocksize, M * N, A_in.dtype, table)

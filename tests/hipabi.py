@@ -37,9 +37,10 @@ def lib():
         l.fp4_hip_code_table.argtypes = [i32, vp]
         l.fp4_hip_dequantize_blockwise.argtypes = [vp, vp, vp, i32, i64, i32, i32, vp]
         l.fp4_hip_gemv.argtypes = [vp, vp, vp, vp, vp, i64, i64, i32, i32, vp]
+        l.fp4_hip_gemv_partial.argtypes = [vp, vp, vp, vp, i64, i64, i32, i32, vp]
         l.fp4_hip_quantize_blockwise.argtypes = [vp, i32, vp, vp, i64, i32, vp]
         l.fp4_hip_set_variant.argtypes = [ctypes.c_char_p, i32]
-        for f in (l.fp4_hip_code_table, l.fp4_hip_dequantize_blockwise, l.fp4_hip_gemv, l.fp4_hip_quantize_blockwise,
+        for f in (l.fp4_hip_code_table, l.fp4_hip_dequantize_blockwise, l.fp4_hip_gemv, l.fp4_hip_gemv_partial, l.fp4_hip_quantize_blockwise,
                   l.fp4_hip_set_variant):
             f.restype = i32
         _lib = l
@@ -71,6 +72,13 @@ def gemv(x: torch.Tensor, packed: torch.Tensor, absmax: torch.Tensor, M: int, K:
          bias: torch.Tensor | None = None) -> torch.Tensor:
     out = torch.empty(M, dtype=x.dtype, device=x.device)
     rc = lib().fp4_hip_gemv(_ptr(x), _ptr(packed), _ptr(absmax), _ptr(bias), _ptr(out), M, K, blocksize, DT[x.dtype], _stream())
+    assert rc == OK, (rc, last_error())
+    return out
+
+
+def gemv_partial(x: torch.Tensor, packed: torch.Tensor, absmax: torch.Tensor, M: int, K: int, blocksize: int) -> torch.Tensor:
+    out = torch.empty(M, dtype=torch.float32, device=x.device)
+    rc = lib().fp4_hip_gemv_partial(_ptr(x), _ptr(packed), _ptr(absmax), _ptr(out), M, K, blocksize, DT[x.dtype], _stream())
     assert rc == OK, (rc, last_error())
     return out
 

@@ -166,3 +166,30 @@ def test_torch_ext_gemv_shapes_and_errors():
         pkg.gemm_4bit_inference(torch.zeros(1, K, device=dev(), dtype=torch.float16), B, absmax, code, 64, torch.bfloat16, [M, K])
     with pytest.raises(RuntimeError, match="fp32 absmax"):
         pkg.gemm_4bit_inference(torch.zeros(1, K, device=dev(), dtype=torch.float16), B, absmax.half(), code, 64, torch.float16, [M, K])
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_partial_f32_output_and_k_split_sum(dtype):
+    """fp4_hip_gemv_partial: the raw f32 accumulator; column shards (re-packed as torch_bnb_fp4.parallel does)
+    sum to the full product - the data path of the row-parallel layer, minus the all-reduce."""
+    import torch_bnb_fp4.parallel as par
+
+    M, K, G = 512, 4096, 8
+    packed, am, x = make_case(M, K, seed=77)
+    x_t = torch_values(x, dtype)
+    P, A = to_dev(packed).view(-1, 1), to_dev(am)
+    full = hipabi.gemv_partial(x_t, P, A, M, K, 64)
+    xv = x_t.float().cpu().numpy().astype(np.float64)
+    exact = c_oracle.gemv_f64(xv, packed, am, M, K, 64)
+    scale = np.abs(o.dequantize_f32(packed, am, 64, M * K).reshape(M, K).astype(np.float64)) @ np.abs(xv)
+    assert full.dtype == torch.float32
+    assert (np.abs(full.cpu().numpy() - exact) <= 1e-5 * scale).all()
+    acc = torch.zeros(M, dtype=torch.float32, device=dev())
+    for r in range(G):
+        p, a, (m, ks) = par.shard_cols(P, A, (M, K), 64, r, G)
+        acc += hipabi.gemv_partial(x_t[r * ks:(r + 1) * ks].contiguous(), p, a, m, ks, 64)
+    assert (np.abs(acc.cpu().numpy() - exact) <= 1e-5 * scale).all()
+    # row shards are plain slices: concatenated shard outputs == the unsharded GEMV, bit for bit
+    y = hipabi.gemv(x_t, P, A, M, K, 64)
+    ys = [hipabi.gemv(x_t, *par.shard_rows(P, A, (M, K), 64, r, G)[:2], M // G, K, 64) for r in range(G)]
+    assert torch.equal(torch.cat(ys), y)

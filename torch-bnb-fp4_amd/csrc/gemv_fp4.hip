@@ -93,7 +93,11 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 template <int DT>
-__device__ __forceinline__ void store_row(uint16_t *out, const uint16_t *bias, int row, float sum) {
+__device__ __forceinline__ void store_row(uint16_t *out, const uint16_t *bias, int row, float sum, int out_f32 = 0) {
+    if (out_f32) {  // K-split partial: the raw f32 accumulator, summed across shards before any rounding
+        reinterpret_cast<float *>(out)[row] = sum;
+        return;
+    }
     uint16_t t = from_f32<DT>(sum);
     // reference: out = T(gemv); out += bias  (torch_bnb_fp4/__init__.py:608-613) -> two roundings
     if (bias) t = from_f32<DT>(to_f32<DT>(t) + to_f32<DT>(bias[row]));
@@ -162,7 +166,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemv16_kernel(const uint16_t *__re
                                                             const uint8_t *__restrict__ W,
                                                             const float *__restrict__ absmax,
                                                             const uint16_t *__restrict__ bias,
-                                                            uint16_t *__restrict__ out, int M, int K, int bs_shift) {
+                                                            uint16_t *__restrict__ out, int M, int K, int bs_shift,
+                                                            int out_f32) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_x[];
     u32x4 *s_x4 = reinterpret_cast<u32x4 *>(s_x);
     const int tid = threadIdx.x;
@@ -224,7 +229,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv16_kernel(const uint16_t *__re
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
         const float total = wave_sum(acc[r]) * (1.0f / 12.0f);
-        if (lane == 0 && row0 + r < M) store_row<DT>(out, bias, row0 + r, total);
+        if (lane == 0 && row0 + r < M) store_row<DT>(out, bias, row0 + r, total, out_f32);
     }
 }
 
@@ -243,7 +248,7 @@ template <int DT, int KSPLIT, int G, int ITERS>
 __global__ __launch_bounds__(256) void gemv16_regx_kernel(const uint16_t *__restrict__ x, const uint8_t *__restrict__ W,
                                                           const float *__restrict__ absmax,
                                                           const uint16_t *__restrict__ bias, uint16_t *__restrict__ out,
-                                                          int M, int K, int bs_shift) {
+                                                          int M, int K, int bs_shift, int out_f32) {
     constexpr int RG = 4 / KSPLIT;               // row-pair groups per workgroup
     constexpr int kRowsPerBlock = 2 * RG * ITERS;
     __shared__ float s_part[kRowsPerBlock][KSPLIT];
@@ -330,7 +335,7 @@ __global__ __launch_bounds__(256) void gemv16_regx_kernel(const uint16_t *__rest
         p += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, p), 0x401F));
         if constexpr (KSPLIT == 1) {
             const int row = row_base + rowi[it];
-            if (l32 == 0 && row < M) store_row<DT>(out, bias, row, p * (1.0f / 12.0f));
+            if (l32 == 0 && row < M) store_row<DT>(out, bias, row, p * (1.0f / 12.0f), out_f32);
         } else {
             if (l32 == 0) s_part[rowi[it]][kw] = p;
         }
@@ -342,7 +347,7 @@ __global__ __launch_bounds__(256) void gemv16_regx_kernel(const uint16_t *__rest
 #pragma unroll
             for (int k = 0; k < KSPLIT; ++k) t += s_part[tid][k];
             const int row = row_base + tid;
-            if (row < M) store_row<DT>(out, bias, row, t * (1.0f / 12.0f));
+            if (row < M) store_row<DT>(out, bias, row, t * (1.0f / 12.0f), out_f32);
         }
     }
 }
@@ -416,7 +421,7 @@ template <int DT>
 __global__ __launch_bounds__(256) void gemv_generic_kernel(const void *__restrict__ xv, const uint8_t *__restrict__ W,
                                                            const float *__restrict__ absmax, const void *__restrict__ biasv,
                                                            void *__restrict__ outv, int M, int64_t K, int blocksize,
-                                                           CodeTable tbl) {
+                                                           CodeTable tbl, int out_f32) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
@@ -443,7 +448,7 @@ __global__ __launch_bounds__(256) void gemv_generic_kernel(const void *__restric
             const float *bias = reinterpret_cast<const float *>(biasv);
             reinterpret_cast<float *>(outv)[row] = bias ? total + bias[row] : total;
         } else {
-            store_row<DT>(reinterpret_cast<uint16_t *>(outv), reinterpret_cast<const uint16_t *>(biasv), row, total);
+            store_row<DT>(reinterpret_cast<uint16_t *>(outv), reinterpret_cast<const uint16_t *>(biasv), row, total, out_f32);
         }
     }
 }
@@ -466,24 +471,24 @@ int ensure_lds(Kern kern, size_t lds_bytes) {
 
 template <int DT, int ROWS, int WAVES, int UNROLL>
 int launch16(const void *x, const uint8_t *W, const float *absmax, const void *bias, void *out, int M, int K, int bs_shift,
-             hipStream_t stream) {
+             int out_f32, hipStream_t stream) {
     auto kern = gemv16_kernel<DT, ROWS, WAVES, UNROLL>;
     const size_t lds = size_t(K) * 2;
     if (int rc = ensure_lds(kern, lds)) return rc;
     const int rows_per_block = ROWS * WAVES;
     const unsigned blocks = (unsigned)((M + rows_per_block - 1) / rows_per_block);
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(WAVES * 64), lds, stream, reinterpret_cast<const uint16_t *>(x), W, absmax,
-                       reinterpret_cast<const uint16_t *>(bias), reinterpret_cast<uint16_t *>(out), M, K, bs_shift);
+                       reinterpret_cast<const uint16_t *>(bias), reinterpret_cast<uint16_t *>(out), M, K, bs_shift, out_f32);
     return FP4_OK;
 }
 
 template <int DT>
 int dispatch16(int variant, const void *x, const uint8_t *W, const float *absmax, const void *bias, void *out, int M, int K,
-               int bs_shift, hipStream_t stream) {
+               int bs_shift, int out_f32, hipStream_t stream) {
     switch (variant) {
 #define FP4_V(R, Wv, U)                  \
     case (R | (Wv << 8) | (U << 16)):    \
-        return launch16<DT, R, Wv, U>(x, W, absmax, bias, out, M, K, bs_shift, stream);
+        return launch16<DT, R, Wv, U>(x, W, absmax, bias, out, M, K, bs_shift, out_f32, stream);
         FP4_V(1, 4, 1) FP4_V(1, 4, 2) FP4_V(2, 4, 1) FP4_V(2, 4, 2) FP4_V(4, 4, 1) FP4_V(4, 4, 2)
         FP4_V(1, 8, 1) FP4_V(1, 8, 2) FP4_V(2, 8, 1) FP4_V(2, 8, 2) FP4_V(4, 8, 1) FP4_V(4, 8, 2)
         FP4_V(1, 16, 2) FP4_V(2, 16, 2)
@@ -498,21 +503,21 @@ constexpr int kRegxFlag = 1 << 24;
 
 template <int DT, int KSPLIT, int G, int ITERS>
 int launch_regx(const void *x, const uint8_t *W, const float *absmax, const void *bias, void *out, int M, int K, int bs_shift,
-                hipStream_t stream) {
+                int out_f32, hipStream_t stream) {
     constexpr int rows_per_block = 2 * (4 / KSPLIT) * ITERS;
     const unsigned blocks = (unsigned)((M + rows_per_block - 1) / rows_per_block);
     hipLaunchKernelGGL((gemv16_regx_kernel<DT, KSPLIT, G, ITERS>), dim3(blocks), dim3(256), 0, stream,
                        reinterpret_cast<const uint16_t *>(x), W, absmax, reinterpret_cast<const uint16_t *>(bias),
-                       reinterpret_cast<uint16_t *>(out), M, K, bs_shift);
+                       reinterpret_cast<uint16_t *>(out), M, K, bs_shift, out_f32);
     return FP4_OK;
 }
 
 // K decides the band split and the x-slice depth; ITERS (row pairs per group) is the tunable.
 template <int DT>
 int dispatch_regx(int iters, const void *x, const uint8_t *W, const float *absmax, const void *bias, void *out, int M, int K,
-                  int bs_shift, hipStream_t stream) {
+                  int bs_shift, int out_f32, hipStream_t stream) {
     const int C = K >> 5;
-#define FP4_RX(KS, GG, IT) return launch_regx<DT, KS, GG, IT>(x, W, absmax, bias, out, M, K, bs_shift, stream)
+#define FP4_RX(KS, GG, IT) return launch_regx<DT, KS, GG, IT>(x, W, absmax, bias, out, M, K, bs_shift, out_f32, stream)
 #define FP4_RX_IT(KS, GG)          \
     switch (iters) {               \
         case 1: FP4_RX(KS, GG, 1); \
@@ -557,10 +562,10 @@ int default_variant16(int M, int K) {
 
 template <int DT>
 int run_generic(const void *x, const uint8_t *W, const float *absmax, const void *bias, void *out, int64_t M, int64_t K,
-                int blocksize, hipStream_t stream) {
+                int blocksize, int out_f32, hipStream_t stream) {
     const CodeTable tbl = make_table(FP4_TABLE_CODEBOOK);
     hipLaunchKernelGGL((gemv_generic_kernel<DT>), dim3((unsigned)((M + 3) / 4)), dim3(256), 0, stream, x, W, absmax, bias,
-                       out, (int)M, K, blocksize, tbl);
+                       out, (int)M, K, blocksize, tbl, out_f32);
     return FP4_OK;
 }
 
@@ -570,9 +575,10 @@ void set_gemv_variant(int v) { g_gemv_variant = v; }
 
 }  // namespace fp4
 
-extern "C" int fp4_hip_gemv(const void *x, const uint8_t *packed, const float *absmax, const void *bias, void *out,
-                            int64_t M, int64_t K, int blocksize, int dtype, void *stream) {
-    using namespace fp4;
+namespace fp4 {
+namespace {
+int gemv_entry(const void *x, const uint8_t *packed, const float *absmax, const void *bias, void *out, int64_t M, int64_t K,
+               int blocksize, int dtype, int out_f32, void *stream) {
     if (M < 0 || K < 0 || (K & 1) || blocksize < 2 || (blocksize & 1)) {
         set_error("fp4_hip_gemv: M=%lld K=%lld blocksize=%d (need M,K >= 0, even K, even blocksize >= 2)", (long long)M,
                   (long long)K, blocksize);
@@ -605,14 +611,14 @@ extern "C" int fp4_hip_gemv(const void *x, const uint8_t *packed, const float *a
         if (variant & kRegxFlag) {
             const int iters = variant & 0xFF;
             rc = dtype == FP4_DTYPE_F16
-                     ? dispatch_regx<FP4_DTYPE_F16>(iters, x, packed, absmax, bias, out, (int)M, (int)K, bs_shift, s)
-                     : dispatch_regx<FP4_DTYPE_BF16>(iters, x, packed, absmax, bias, out, (int)M, (int)K, bs_shift, s);
+                     ? dispatch_regx<FP4_DTYPE_F16>(iters, x, packed, absmax, bias, out, (int)M, (int)K, bs_shift, out_f32, s)
+                     : dispatch_regx<FP4_DTYPE_BF16>(iters, x, packed, absmax, bias, out, (int)M, (int)K, bs_shift, out_f32, s);
             if (rc == -1) variant = 1 | (8 << 8) | (2 << 16);  // K too large for register-resident x
         }
         if (rc == -1)
             rc = dtype == FP4_DTYPE_F16
-                     ? dispatch16<FP4_DTYPE_F16>(variant, x, packed, absmax, bias, out, (int)M, (int)K, bs_shift, s)
-                     : dispatch16<FP4_DTYPE_BF16>(variant, x, packed, absmax, bias, out, (int)M, (int)K, bs_shift, s);
+                     ? dispatch16<FP4_DTYPE_F16>(variant, x, packed, absmax, bias, out, (int)M, (int)K, bs_shift, out_f32, s)
+                     : dispatch16<FP4_DTYPE_BF16>(variant, x, packed, absmax, bias, out, (int)M, (int)K, bs_shift, out_f32, s);
     } else if (fast) {
         auto kern = gemv32_kernel<1, 4>;
         const size_t lds = size_t(K) * 4;
@@ -624,16 +630,28 @@ extern "C" int fp4_hip_gemv(const void *x, const uint8_t *packed, const float *a
     } else {
         switch (dtype) {
             case FP4_DTYPE_F16:
-                rc = run_generic<FP4_DTYPE_F16>(x, packed, absmax, bias, out, M, K, blocksize, s);
+                rc = run_generic<FP4_DTYPE_F16>(x, packed, absmax, bias, out, M, K, blocksize, out_f32, s);
                 break;
             case FP4_DTYPE_BF16:
-                rc = run_generic<FP4_DTYPE_BF16>(x, packed, absmax, bias, out, M, K, blocksize, s);
+                rc = run_generic<FP4_DTYPE_BF16>(x, packed, absmax, bias, out, M, K, blocksize, out_f32, s);
                 break;
             default:
-                rc = run_generic<FP4_DTYPE_F32>(x, packed, absmax, bias, out, M, K, blocksize, s);
+                rc = run_generic<FP4_DTYPE_F32>(x, packed, absmax, bias, out, M, K, blocksize, out_f32, s);
                 break;
         }
     }
     if (rc != FP4_OK) return rc;
     return check_launch("fp4_hip_gemv");
+}
+}  // namespace
+}  // namespace fp4
+
+extern "C" int fp4_hip_gemv(const void *x, const uint8_t *packed, const float *absmax, const void *bias, void *out,
+                            int64_t M, int64_t K, int blocksize, int dtype, void *stream) {
+    return fp4::gemv_entry(x, packed, absmax, bias, out, M, K, blocksize, dtype, 0, stream);
+}
+
+extern "C" int fp4_hip_gemv_partial(const void *x, const uint8_t *packed, const float *absmax, float *out_f32, int64_t M,
+                                    int64_t K, int blocksize, int x_dtype, void *stream) {
+    return fp4::gemv_entry(x, packed, absmax, nullptr, out_f32, M, K, blocksize, x_dtype, 1, stream);
 }

@@ -12,7 +12,7 @@
 //   * launch / dtype failures raise instead of printf (csrc/dequant_fp4_optimized.cu:48-53,201-203);
 //   * qlinear_codebook* dequantise all M*N elements (the reference passes the BYTE count,
 //     csrc/torch_fp4.cpp:90,101, leaving half of the weight uninitialised).
-// Extra exports (not in the reference): gemv_fp4_bias, quantize_fp4, set_kernel_variant, code_table.
+// Extra exports (not in the reference): gemv_fp4_bias, gemv_fp4_partial, quantize_fp4, set_kernel_variant, code_table.
 #include <c10/core/DeviceGuard.h>
 #include <c10/hip/HIPStream.h>
 #include <torch/extension.h>
@@ -180,6 +180,24 @@ torch::Tensor gemv_fp4_bias(torch::Tensor A, torch::Tensor B, torch::Tensor absm
     return gemv_impl(A, B, absmax, datatype, blocksize, dtype, Bshape, bias);
 }
 
+// f32 partial sums of a K-split shard: [1, m] float32 (see fp4_hip_gemv_partial)
+torch::Tensor gemv_fp4_partial(torch::Tensor A, torch::Tensor B, torch::Tensor absmax, int blocksize, std::vector<uint32_t> Bshape) {
+    check_gpu_contiguous(A, "A");
+    check_gpu_contiguous(B, "B");
+    check_gpu_contiguous(absmax, "absmax");
+    TORCH_CHECK(Bshape.size() == 2, "Bshape must be [out_features, in_features_of_this_shard]");
+    const int64_t m = Bshape[0], k = Bshape[1];
+    TORCH_CHECK(A.numel() == k, "gemv_fp4_partial is batch-1 only: activation has ", A.numel(), " elements, shard K is ", k);
+    TORCH_CHECK(B.dtype() == torch::kUInt8 && B.numel() * 2 >= m * k, "B too small for a ", m, "x", k, " shard");
+    TORCH_CHECK(absmax.scalar_type() == torch::kFloat32 && absmax.numel() * int64_t(blocksize) >= m * k, "absmax too small");
+    const int dt = to_fp4_dtype(A.scalar_type(), "gemv_fp4_partial");
+    torch::Tensor out = torch::empty({1, m}, A.options().dtype(torch::kFloat32));
+    c10::DeviceGuard guard(A.device());
+    check_status(fp4_hip_gemv_partial(A.data_ptr(), B.data_ptr<uint8_t>(), absmax.data_ptr<float>(), out.data_ptr<float>(), m, k,
+                                      blocksize, dt, current_stream(A)));
+    return out;
+}
+
 // bitsandbytes-format FP4 quantisation of a float tensor: returns (packed uint8[ceil(n/2), 1], absmax float32[ceil(n/bs)])
 std::tuple<torch::Tensor, torch::Tensor> quantize_fp4(torch::Tensor W, int blocksize) {
     check_gpu_contiguous(W, "W");
@@ -223,6 +241,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("qlinear_codebook_bias", &qlinear_codebook_bias, "codebook dequant + linear + bias");
     // extras
     m.def("gemv_fp4_bias", &gemv_fp4_bias, "gemv_fp4 with the bias add fused into the epilogue");
+    m.def("gemv_fp4_partial", &gemv_fp4_partial, "f32 partial sums of a K-split shard: (A, B, absmax, blocksize, Bshape)");
     m.def("quantize_fp4", &quantize_fp4, "blockwise FP4 quantiser: (W, blocksize) -> (packed, absmax)");
     m.def("code_table", &code_table, "16-entry code table as a CPU float tensor");
     m.def("set_kernel_variant", &set_kernel_variant, "benchmark hook: select a kernel geometry");

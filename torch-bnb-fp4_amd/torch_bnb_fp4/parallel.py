@@ -1,0 +1,112 @@
+"""Tensor-parallel use of FP4 Linear weights across the GPUs of one node (one process per GPU,
+``torch.distributed`` with the ``nccl`` backend = RCCL over xGMI).
+
+The reference has no multi-GPU code at all; this module is the SURVEY section 8e design:
+
+* quant blocks are flat over the row-major weight and ``K % blocksize == 0``, so a **row range** of W is a
+  contiguous slice of both ``packed`` and ``absmax`` -> M-split ("column-parallel") shards need no re-packing and
+  no collective for the GEMV itself (outputs are disjoint; an all-gather only if the consumer wants all of y);
+* a **column range** is strided -> K-split ("row-parallel") shards are re-packed once at load time into their own
+  contiguous ``[M, K/G/2]`` bytes + ``[M*K/G/bs]`` scales; each rank produces a full-length f32 partial
+  (``gemv_fp4_partial``) and the partials are summed with one all-reduce (16 KiB at M = 4096: latency-bound),
+  then rounded to the activation dtype once.
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+from torch import nn
+
+from ._ext import ext
+from .dtypes import ScalarType
+from .nn import QuantState, fp4_code
+from .quant_data import QuantData
+
+
+def shard_rows(packed: torch.Tensor, absmax: torch.Tensor, shape: Sequence[int], blocksize: int, rank: int, world: int
+               ) -> Tuple[torch.Tensor, torch.Tensor, Tuple[int, int]]:
+    """Rows ``[rank*M/world, (rank+1)*M/world)`` of an FP4 weight: plain contiguous slices (views)."""
+    M, K = int(shape[0]), int(shape[1])
+    if M % world or K % blocksize or K % 2:
+        raise ValueError(f"cannot row-shard a {M}x{K} weight (blocksize {blocksize}) {world} ways")
+    rows = M // world
+    p = packed.reshape(-1)[rank * rows * K // 2:(rank + 1) * rows * K // 2].reshape(-1, 1)
+    a = absmax.reshape(-1)[rank * rows * K // blocksize:(rank + 1) * rows * K // blocksize]
+    return p, a, (rows, K)
+
+
+def shard_cols(packed: torch.Tensor, absmax: torch.Tensor, shape: Sequence[int], blocksize: int, rank: int, world: int
+               ) -> Tuple[torch.Tensor, torch.Tensor, Tuple[int, int]]:
+    """Columns ``[rank*K/world, (rank+1)*K/world)`` re-packed into a contiguous ``[M, K/world]`` FP4 weight."""
+    M, K = int(shape[0]), int(shape[1])
+    if K % world or (K // world) % blocksize or (K // world) % 2:
+        raise ValueError(f"cannot column-shard a {M}x{K} weight (blocksize {blocksize}) {world} ways")
+    ks = K // world
+    p = packed.reshape(M, K // 2)[:, rank * ks // 2:(rank + 1) * ks // 2].contiguous().reshape(-1, 1)
+    a = absmax.reshape(M, K // blocksize)[:, rank * ks // blocksize:(rank + 1) * ks // blocksize].contiguous().reshape(-1)
+    return p, a, (M, ks)
+
+
+def _quant_data(packed, absmax, shape, blocksize, bias, use_codebook_dequant=True) -> QuantData:
+    state = QuantState(absmax, shape, fp4_code().to(packed.device), blocksize)
+    return QuantData(packed, state, state.shape, original_lin=None, bias=bias, use_codebook_dequant=use_codebook_dequant)
+
+
+class ColumnParallelFP4Linear(nn.Module):
+    """M-split: this rank owns ``out_features / world`` rows (and that slice of the bias)."""
+
+    def __init__(self, packed, absmax, shape, blocksize: int = 64, bias: Optional[torch.Tensor] = None, group=None,
+                 gather_output: bool = True):
+        super().__init__()
+        self.group = group
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        p, a, local = shard_rows(packed, absmax, shape, blocksize, self.rank, self.world)
+        b = None if bias is None else bias.reshape(-1)[self.rank * local[0]:(self.rank + 1) * local[0]]
+        self.quant_data = _quant_data(p, a, local, blocksize, b)
+        self.gather_output = gather_output
+        self.out_features, self.in_features = int(shape[0]), int(shape[1])
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        y = self.quant_data.forward(x)
+        if not self.gather_output or self.world == 1:
+            return y
+        parts = [torch.empty_like(y) for _ in range(self.world)]
+        dist.all_gather(parts, y.contiguous(), group=self.group)
+        return torch.cat(parts, dim=-1)
+
+
+class RowParallelFP4Linear(nn.Module):
+    """K-split: this rank owns ``in_features / world`` columns; outputs are summed across ranks in f32."""
+
+    def __init__(self, packed, absmax, shape, blocksize: int = 64, bias: Optional[torch.Tensor] = None, group=None,
+                 input_is_parallel: bool = False):
+        super().__init__()
+        self.group = group
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        p, a, local = shard_cols(packed, absmax, shape, blocksize, self.rank, self.world)
+        self.quant_data = _quant_data(p, a, local, blocksize, None)
+        self.bias = bias
+        self.blocksize = blocksize
+        self.local_shape = local
+        self.input_is_parallel = input_is_parallel
+        self.out_features, self.in_features = int(shape[0]), int(shape[1])
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        ks = self.local_shape[1]
+        xs = x if self.input_is_parallel else x[..., self.rank * ks:(self.rank + 1) * ks]
+        qd = self.quant_data
+        if xs.numel() == ks:  # single token: fused GEMV, raw f32 accumulator out
+            part = ext.gemv_fp4_partial(xs.reshape(1, ks).contiguous(), qd.A.t(), qd.absmax, self.blocksize, list(self.local_shape))
+            part = part.view(*x.shape[:-1], self.out_features)
+        else:  # batch / sequence: dequant + GEMM, partial kept in f32 for the sum
+            if not qd.compute_dtype_set:
+                qd.set_compute_type(xs)
+            part = torch.nn.functional.linear(xs, qd.dequantize()).float()
+        if self.world > 1:
+            dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.group)
+        y = part.to(x.dtype)
+        if self.bias is not None:
+            y = y + self.bias.to(x.dtype)
+        return y
