@@ -54,6 +54,13 @@ class FakeExt:
         self.calls.append("gemv_fp4_bias")
         return self._gemv(A, B, absmax, blocksize, dtype, Bshape, bias)
 
+    def gemm_small_fp4(self, A, B, absmax, blocksize, Bshape, bias):
+        self.calls.append("gemm_small_fp4")
+        M, K = Bshape
+        w = torch.from_numpy(o.dequantize_f32(B.numpy().reshape(-1), absmax.numpy(), blocksize, M * K)).view(M, K)
+        y = torch.nn.functional.linear(A.float(), w, None if bias is None else bias.float())
+        return y.to(A.dtype)
+
     def gemv_fp4_partial(self, A, B, absmax, blocksize, Bshape):
         self.calls.append("gemv_fp4_partial")
         M, K = Bshape

@@ -38,6 +38,8 @@ def lib():
         l.fp4_hip_dequantize_blockwise.argtypes = [vp, vp, vp, i32, i64, i32, i32, vp]
         l.fp4_hip_gemv.argtypes = [vp, vp, vp, vp, vp, i64, i64, i32, i32, vp]
         l.fp4_hip_gemv_partial.argtypes = [vp, vp, vp, vp, i64, i64, i32, i32, vp]
+        l.fp4_hip_gemm_small.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, i32, i32, vp]
+        l.fp4_hip_gemm_small.restype = i32
         l.fp4_hip_quantize_blockwise.argtypes = [vp, i32, vp, vp, i64, i32, vp]
         l.fp4_hip_set_variant.argtypes = [ctypes.c_char_p, i32]
         for f in (l.fp4_hip_code_table, l.fp4_hip_dequantize_blockwise, l.fp4_hip_gemv, l.fp4_hip_gemv_partial, l.fp4_hip_quantize_blockwise,
@@ -74,6 +76,17 @@ def gemv(x: torch.Tensor, packed: torch.Tensor, absmax: torch.Tensor, M: int, K:
     rc = lib().fp4_hip_gemv(_ptr(x), _ptr(packed), _ptr(absmax), _ptr(bias), _ptr(out), M, K, blocksize, DT[x.dtype], _stream())
     assert rc == OK, (rc, last_error())
     return out
+
+
+def gemm_small(x: torch.Tensor, packed: torch.Tensor, absmax: torch.Tensor, M: int, K: int, blocksize: int,
+               bias: torch.Tensor | None = None, expect_ok: bool = True):
+    B = x.numel() // K
+    out = torch.empty(B, M, dtype=x.dtype, device=x.device)
+    rc = lib().fp4_hip_gemm_small(_ptr(x), _ptr(packed), _ptr(absmax), _ptr(bias), _ptr(out), B, M, K, blocksize, DT[x.dtype], _stream())
+    if expect_ok:
+        assert rc == OK, (rc, last_error())
+        return out
+    return rc
 
 
 def gemv_partial(x: torch.Tensor, packed: torch.Tensor, absmax: torch.Tensor, M: int, K: int, blocksize: int) -> torch.Tensor:

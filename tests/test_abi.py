@@ -12,7 +12,7 @@ from oracle import fp4_oracle as o
 def test_header_symbols_are_exported():
     declared = hipabi.declared_symbols()
     assert set(declared) >= {"fp4_hip_abi_version", "fp4_hip_last_error", "fp4_hip_code_table", "fp4_hip_dequantize_blockwise",
-                             "fp4_hip_gemv", "fp4_hip_gemv_partial", "fp4_hip_quantize_blockwise", "fp4_hip_set_variant"}
+                             "fp4_hip_gemv", "fp4_hip_gemv_partial", "fp4_hip_gemm_small", "fp4_hip_quantize_blockwise", "fp4_hip_set_variant"}
     l = hipabi.lib()
     for name in declared:
         assert hasattr(l, name), name

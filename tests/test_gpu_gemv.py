@@ -193,3 +193,29 @@ def test_partial_f32_output_and_k_split_sum(dtype):
     y = hipabi.gemv(x_t, P, A, M, K, 64)
     ys = [hipabi.gemv(x_t, *par.shard_rows(P, A, (M, K), 64, r, G)[:2], M // G, K, 64) for r in range(G)]
     assert torch.equal(torch.cat(ys), y)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B", [1, 2, 3, 4, 5, 8])
+@pytest.mark.parametrize("M,K", [(4096, 4096), (1024, 4096), (2048, 768), (66, 2048), (257, 1024), (300, 8192), (40, 14336)])
+def test_small_batch_fused_gemm(dtype, B, M, K):
+    """fp4_hip_gemm_small: 1..8 activation rows against the float64 product, same bar as the GEMV (one rounding)."""
+    packed, am, _ = make_case(M, K, seed=B * 1000 + M)
+    rng = np.random.default_rng(B)
+    x = rng.standard_normal((B, K)).astype(np.float32)
+    bias = rng.standard_normal(M).astype(np.float32) * 0.1
+    x_t, b_t = torch_values(x, dtype), torch_values(bias, dtype)
+    covered = (K // 32 <= 128) or (K // 32 <= 256 and B <= 4) or (K // 32 <= 512 and B <= 2)
+    if not covered:
+        rc = hipabi.gemm_small(x_t, to_dev(packed), to_dev(am), M, K, 64, expect_ok=False)
+        assert rc == hipabi.ERR_UNSUPPORTED and "dequant + GEMM" in hipabi.last_error()
+        return
+    y = hipabi.gemm_small(x_t, to_dev(packed), to_dev(am), M, K, 64, bias=b_t)
+    wabs = np.abs(o.dequantize_f32(packed, am, 64, M * K).reshape(M, K).astype(np.float64))
+    bv = b_t.float().cpu().numpy().astype(np.float64)
+    for b in range(B):
+        xv = x_t[b].float().cpu().numpy().astype(np.float64)
+        exact = c_oracle.gemv_f64(xv, packed, am, M, K, 64) + bv
+        scale = wabs @ np.abs(xv) + np.abs(bv)
+        err = np.abs(y[b].float().cpu().numpy() - exact)
+        assert (err <= HALF_ULP[dtype] * 1.01 * np.abs(exact) + 1e-5 * scale + 1e-30).all(), (b, err.max())

@@ -127,6 +127,21 @@ def test_unfused_bias_and_tree_and_low_precision_paths(fake):
     assert fake.calls == ["qlinear_codebook"]
 
 
+def test_small_batch_opt_in(fake):
+    qd, wq, lin = make_quant_data(64, 128, small_batch_fused=True)
+    x = torch.randn(3, 128).to(torch.bfloat16)
+    y = qd.forward(x)
+    assert fake.calls == ["gemm_small_fp4"] and y.shape == (3, 64)
+    ref = torch.nn.functional.linear(x.float(), wq, lin.bias.float())
+    assert (y.float() - ref).abs().max() <= 6e-2 * max(1.0, ref.abs().max().item())
+    fake.calls.clear()
+    qd.forward(torch.randn(9, 128).to(torch.bfloat16))  # > 8 rows: the reference path
+    assert fake.calls == ["dequantize_fp4_codebook"]
+    fake.calls.clear()
+    qd.forward(torch.randn(1, 128).to(torch.bfloat16))  # single token is still the GEMV
+    assert fake.calls == ["gemv_fp4_bias"]
+
+
 def test_surgery_helpers_cpu():
     assert pkg.check_if_name_contained_in_list("model.lm_head", ["lm_head"])
     assert not pkg.check_if_name_contained_in_list("proj", ["lm_head", "pooler"])

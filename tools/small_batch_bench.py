@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Fused small-batch FP4 GEMM (fp4_hip_gemm_small) vs the reference's batch>1 path (dequant + hipBLASLt GEMM),
+4096x4096 bf16, HBM-cold rotation over 64 weights, HIP-graph replay."""
+import os
+import statistics
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [REPO, os.path.join(REPO, "torch-bnb-fp4_amd"), os.path.join(REPO, "tests")]
+import torch  # noqa: E402
+
+import hipabi  # noqa: E402
+
+M = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+K = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+R, dev, n = 64, torch.device("cuda", 0), M * K
+gen = torch.Generator(device=dev).manual_seed(0)
+packed = [torch.randint(0, 256, (n // 2,), dtype=torch.uint8, device=dev, generator=gen) for _ in range(R)]
+absmax = [torch.rand(n // 64, device=dev, generator=gen) * 0.1 + 0.01 for _ in range(R)]
+wbuf = [torch.empty(M, K, dtype=torch.bfloat16, device=dev) for _ in range(R)]
+
+
+def capture(fn):
+    fn()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        fn()
+    torch.cuda.synchronize()
+    return g.replay
+
+
+def timeit(replay, launches, reps=7):
+    ts = []
+    for _ in range(reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); replay(); b.record(); b.synchronize()
+        ts.append(a.elapsed_time(b) * 1e3 / launches)
+    return statistics.median(ts)
+
+
+for B in (1, 2, 4, 8):
+    x = torch.randn(B, K, device=dev).to(torch.bfloat16)
+    fused = capture(lambda: [hipabi.gemm_small(x, packed[i], absmax[i], M, K, 64) for i in range(R)])
+
+    def ref():
+        for i in range(R):
+            hipabi.dequantize(packed[i], absmax[i], 64, n, torch.bfloat16, out=wbuf[i].view(-1))
+            torch.nn.functional.linear(x, wbuf[i])
+
+    t_f, t_r = timeit(fused, R), timeit(capture(ref), R)
+    print(f"{M}x{K} bf16 batch {B}: fused {t_f:6.2f} us   dequant+hipBLASLt {t_r:6.2f} us   speedup {t_r / t_f:4.1f}x", flush=True)

@@ -501,6 +501,171 @@ int dispatch16(int variant, const void *x, const uint8_t *W, const float *absmax
 
 constexpr int kRegxFlag = 1 << 24;
 
+// ---- small batch (2..8 activation rows): the same register-x geometry with NB x-slices per lane ----------
+// The reference sends every batch > 1 through a full dequant (43 MB written and re-read at 4096x4096) plus a dense
+// GEMM (torch_bnb_fp4/__init__.py:616-617).  For a handful of rows the weight stream can instead be decoded once
+// per nibble and dotted against NB activation rows: traffic stays at the GEMV's 9.45 MB.  One rounding at the end,
+// bias added in f32 before it (what F.linear does for batch > 1).
+template <int DT, int KSPLIT, int G, int ITERS, int NB>
+__global__ __launch_bounds__(256) void gemm16_small_kernel(const uint16_t *__restrict__ x, const uint8_t *__restrict__ W,
+                                                           const float *__restrict__ absmax,
+                                                           const uint16_t *__restrict__ bias, uint16_t *__restrict__ out,
+                                                           int B, int M, int K, int bs_shift) {
+    constexpr int RG = 4 / KSPLIT;
+    constexpr int kRowsPerBlock = 2 * RG * ITERS;
+    __shared__ float s_part[kRowsPerBlock][KSPLIT][NB];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int kw = wave % KSPLIT, rw = wave / KSPLIT;
+    const int half = lane >> 5, l32 = lane & 31;
+    const int C = K >> 5;
+    const int row_base = blockIdx.x * kRowsPerBlock;
+    const u32x4 *Wv = reinterpret_cast<const u32x4 *>(W);
+
+    int cidx[G];
+    bool live[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const int c = g * (32 * KSPLIT) + kw * 32 + l32;
+        live[g] = c < C;
+        cidx[g] = live[g] ? c : C - 1;
+    }
+    u32x4 xd[NB][G][4];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int64_t xrow = int64_t(b < B ? b : B - 1) * (K >> 3);  // in 16-byte pieces; rows past B are computed, not stored
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) xd[b][g][q] = reinterpret_cast<const u32x4 *>(x)[xrow + cidx[g] * 4 + q];
+        }
+    }
+    u32x4 wq[ITERS][G];
+    float am[ITERS][G];
+    int rowi[ITERS];
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int local = 2 * (it * RG + rw) + half;
+        const int row = row_base + local;
+        rowi[it] = local;
+        const int rclamp = row < M ? row : M - 1;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int64_t chunk = int64_t(rclamp) * C + cidx[g];
+            wq[it][g] = __builtin_nontemporal_load(Wv + chunk);
+            const float a = absmax[(chunk << 5) >> bs_shift];
+            am[it][g] = live[g] ? a : 0.0f;
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const u32x4 w = xd[b][g][q];
+                xd[b][g][q].x = perm(w.y, w.x, 0x05040100u);
+                xd[b][g][q].y = perm(w.w, w.z, 0x05040100u);
+                xd[b][g][q].z = perm(w.y, w.x, 0x07060302u);
+                xd[b][g][q].w = perm(w.w, w.z, 0x07060302u);
+            }
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        float p[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) p[b] = 0.0f;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            float s[NB];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) s[b] = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                uint32_t P[4];
+                decode8<DT>(wq[it][g][q], P);  // decoded once, used by every activation row
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    s[b] = dot2<DT>(P[0], xd[b][g][q].x, s[b]);
+                    s[b] = dot2<DT>(P[1], xd[b][g][q].y, s[b]);
+                    s[b] = dot2<DT>(P[2], xd[b][g][q].z, s[b]);
+                    s[b] = dot2<DT>(P[3], xd[b][g][q].w, s[b]);
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < NB; ++b) p[b] = __builtin_fmaf(s[b], am[it][g], p[b]);
+        }
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            float v = p[b];
+            v = dpp_add<0x128>(v);
+            v = dpp_add<0x124>(v);
+            v = dpp_add<0x122>(v);
+            v = dpp_add<0x121>(v);
+            v += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));
+            if (l32 == 0) s_part[rowi[it]][kw][b] = v;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < kRowsPerBlock * NB; i += 256) {
+        const int r = i / NB, b = i % NB;
+        float t = 0.0f;
+#pragma unroll
+        for (int k = 0; k < KSPLIT; ++k) t += s_part[r][k][b];
+        const int row = row_base + r;
+        if (row < M && b < B) {
+            t *= (1.0f / 12.0f);
+            if (bias) t += to_f32<DT>(bias[row]);
+            out[int64_t(b) * M + row] = from_f32<DT>(t);
+        }
+    }
+}
+
+template <int DT, int KSPLIT, int G, int ITERS, int NB>
+int launch_small(const void *x, const uint8_t *W, const float *absmax, const void *bias, void *out, int B, int M, int K,
+                 int bs_shift, hipStream_t stream) {
+    constexpr int rows_per_block = 2 * (4 / KSPLIT) * ITERS;
+    const unsigned blocks = (unsigned)((M + rows_per_block - 1) / rows_per_block);
+    hipLaunchKernelGGL((gemm16_small_kernel<DT, KSPLIT, G, ITERS, NB>), dim3(blocks), dim3(256), 0, stream,
+                       reinterpret_cast<const uint16_t *>(x), W, absmax, reinterpret_cast<const uint16_t *>(bias),
+                       reinterpret_cast<uint16_t *>(out), B, M, K, bs_shift);
+    return FP4_OK;
+}
+
+// returns -1 when the shape is outside what the register budget covers (caller falls back to dequant + GEMM)
+template <int DT>
+int dispatch_small(const void *x, const uint8_t *W, const float *absmax, const void *bias, void *out, int B, int M, int K,
+                   int bs_shift, hipStream_t stream) {
+    const int C = K >> 5;
+    const int nb = B <= 2 ? 2 : (B <= 4 ? 4 : 8);
+#define FP4_SM(KS, GG, NBB) return launch_small<DT, KS, GG, 2, NBB>(x, W, absmax, bias, out, B, M, K, bs_shift, stream)
+#define FP4_SM_NB(KS, GG)       \
+    switch (nb) {               \
+        case 2: FP4_SM(KS, GG, 2); \
+        case 4: FP4_SM(KS, GG, 4); \
+        default: FP4_SM(KS, GG, 8); \
+    }
+    if (C <= 32) {
+        FP4_SM_NB(1, 1)
+    } else if (C <= 64) {
+        FP4_SM_NB(2, 1)
+    } else if (C <= 128) {
+        FP4_SM_NB(4, 1)
+    } else if (C <= 256 && nb <= 4) {
+        switch (nb) {
+            case 2: FP4_SM(4, 2, 2);
+            default: FP4_SM(4, 2, 4);
+        }
+    } else if (C <= 512 && nb <= 2) {
+        FP4_SM(4, 4, 2);
+    }
+#undef FP4_SM_NB
+#undef FP4_SM
+    return -1;
+}
+
 template <int DT, int KSPLIT, int G, int ITERS>
 int launch_regx(const void *x, const uint8_t *W, const float *absmax, const void *bias, void *out, int M, int K, int bs_shift,
                 int out_f32, hipStream_t stream) {
@@ -654,4 +819,34 @@ extern "C" int fp4_hip_gemv(const void *x, const uint8_t *packed, const float *a
 extern "C" int fp4_hip_gemv_partial(const void *x, const uint8_t *packed, const float *absmax, float *out_f32, int64_t M,
                                     int64_t K, int blocksize, int x_dtype, void *stream) {
     return fp4::gemv_entry(x, packed, absmax, nullptr, out_f32, M, K, blocksize, x_dtype, 1, stream);
+}
+
+extern "C" int fp4_hip_gemm_small(const void *x, const uint8_t *packed, const float *absmax, const void *bias, void *out,
+                                  int64_t B, int64_t M, int64_t K, int blocksize, int dtype, void *stream) {
+    using namespace fp4;
+    if (B < 1 || B > 8 || M < 0 || K <= 0) {
+        set_error("fp4_hip_gemm_small: B=%lld M=%lld K=%lld (need 1 <= B <= 8)", (long long)B, (long long)M, (long long)K);
+        return FP4_ERR_INVALID_ARGUMENT;
+    }
+    if (M == 0) return FP4_OK;
+    if (!x || !packed || !absmax || !out) {
+        set_error("fp4_hip_gemm_small: null pointer");
+        return FP4_ERR_INVALID_ARGUMENT;
+    }
+    const int bs_shift = ilog2_exact(blocksize);
+    const uintptr_t align = reinterpret_cast<uintptr_t>(packed) | reinterpret_cast<uintptr_t>(x);
+    const bool ok = (dtype == FP4_DTYPE_F16 || dtype == FP4_DTYPE_BF16) && (K % 32) == 0 && bs_shift >= 5 &&
+                    (K % blocksize) == 0 && (align & 15u) == 0 && M <= (int64_t(1) << 30) && K <= 16384;
+    int rc = -1;
+    if (ok)
+        rc = dtype == FP4_DTYPE_F16 ? dispatch_small<FP4_DTYPE_F16>(x, packed, absmax, bias, out, (int)B, (int)M, (int)K, bs_shift,
+                                                                    static_cast<hipStream_t>(stream))
+                                    : dispatch_small<FP4_DTYPE_BF16>(x, packed, absmax, bias, out, (int)B, (int)M, (int)K,
+                                                                     bs_shift, static_cast<hipStream_t>(stream));
+    if (rc == -1) {
+        set_error("fp4_hip_gemm_small: shape B=%lld M=%lld K=%lld blocksize=%d dtype=%d is not covered; use dequant + GEMM",
+                  (long long)B, (long long)M, (long long)K, blocksize, dtype);
+        return FP4_ERR_UNSUPPORTED;
+    }
+    return check_launch("fp4_hip_gemm_small");
 }

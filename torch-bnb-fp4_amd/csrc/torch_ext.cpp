@@ -12,7 +12,7 @@
 //   * launch / dtype failures raise instead of printf (csrc/dequant_fp4_optimized.cu:48-53,201-203);
 //   * qlinear_codebook* dequantise all M*N elements (the reference passes the BYTE count,
 //     csrc/torch_fp4.cpp:90,101, leaving half of the weight uninitialised).
-// Extra exports (not in the reference): gemv_fp4_bias, gemv_fp4_partial, quantize_fp4, set_kernel_variant, code_table.
+// Extra exports (not in the reference): gemv_fp4_bias, gemm_small_fp4, gemv_fp4_partial, quantize_fp4, set_kernel_variant, code_table.
 #include <c10/core/DeviceGuard.h>
 #include <c10/hip/HIPStream.h>
 #include <torch/extension.h>
@@ -180,6 +180,37 @@ torch::Tensor gemv_fp4_bias(torch::Tensor A, torch::Tensor B, torch::Tensor absm
     return gemv_impl(A, B, absmax, datatype, blocksize, dtype, Bshape, bias);
 }
 
+// fused small-batch product: A [..., K] with 1..8 rows in total -> [..., m]; raises if the shape is not covered
+torch::Tensor gemm_small_fp4(torch::Tensor A, torch::Tensor B, torch::Tensor absmax, int blocksize, std::vector<uint32_t> Bshape,
+                             c10::optional<torch::Tensor> bias) {
+    check_gpu_contiguous(A, "A");
+    check_gpu_contiguous(B, "B");
+    check_gpu_contiguous(absmax, "absmax");
+    TORCH_CHECK(Bshape.size() == 2, "Bshape must be [out_features, in_features]");
+    const int64_t m = Bshape[0], k = Bshape[1];
+    TORCH_CHECK(A.dim() >= 1 && A.size(-1) == k, "gemm_small_fp4: last dim of the activation must be in_features = ", k);
+    const int64_t rows = A.numel() / k;
+    TORCH_CHECK(rows >= 1 && rows <= 8, "gemm_small_fp4 covers 1..8 activation rows, got ", rows);
+    TORCH_CHECK(B.dtype() == torch::kUInt8 && B.numel() * 2 >= m * k, "B too small for a ", m, "x", k, " weight");
+    TORCH_CHECK(absmax.scalar_type() == torch::kFloat32 && absmax.numel() * int64_t(blocksize) >= m * k, "absmax too small");
+    const int dt = to_fp4_dtype(A.scalar_type(), "gemm_small_fp4");
+    auto shape = A.sizes().vec();
+    shape.back() = m;
+    torch::Tensor out = torch::empty(shape, A.options());
+    const void *bias_ptr = nullptr;
+    torch::Tensor bias_c;
+    if (bias.has_value()) {
+        TORCH_CHECK(bias->is_cuda() && bias->numel() == m && bias->scalar_type() == A.scalar_type(), "bias must be a [", m,
+                    "] tensor of the activation dtype");
+        bias_c = bias->contiguous();
+        bias_ptr = bias_c.data_ptr();
+    }
+    c10::DeviceGuard guard(A.device());
+    check_status(fp4_hip_gemm_small(A.data_ptr(), B.data_ptr<uint8_t>(), absmax.data_ptr<float>(), bias_ptr, out.data_ptr(), rows, m,
+                                    k, blocksize, dt, current_stream(A)));
+    return out;
+}
+
 // f32 partial sums of a K-split shard: [1, m] float32 (see fp4_hip_gemv_partial)
 torch::Tensor gemv_fp4_partial(torch::Tensor A, torch::Tensor B, torch::Tensor absmax, int blocksize, std::vector<uint32_t> Bshape) {
     check_gpu_contiguous(A, "A");
@@ -241,6 +272,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("qlinear_codebook_bias", &qlinear_codebook_bias, "codebook dequant + linear + bias");
     // extras
     m.def("gemv_fp4_bias", &gemv_fp4_bias, "gemv_fp4 with the bias add fused into the epilogue");
+    m.def("gemm_small_fp4", &gemm_small_fp4, "fused FP4 product for 1..8 activation rows: (A, B, absmax, blocksize, Bshape, bias|None)");
     m.def("gemv_fp4_partial", &gemv_fp4_partial, "f32 partial sums of a K-split shard: (A, B, absmax, blocksize, Bshape)");
     m.def("quantize_fp4", &quantize_fp4, "blockwise FP4 quantiser: (W, blocksize) -> (packed, absmax)");
     m.def("code_table", &code_table, "16-entry code table as a CPU float tensor");

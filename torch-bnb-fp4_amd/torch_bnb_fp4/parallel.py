@@ -49,6 +49,19 @@ def shard_cols(packed: torch.Tensor, absmax: torch.Tensor, shape: Sequence[int],
     return p, a, (M, ks)
 
 
+def concat_rows(weights: Sequence[Tuple[torch.Tensor, torch.Tensor, Sequence[int]]], blocksize: int
+                ) -> Tuple[torch.Tensor, torch.Tensor, Tuple[int, int]]:
+    """Stack FP4 weights that share ``in_features`` along the output dimension (fused QKV / gate-up projections):
+    rows are independent and ``K % blocksize == 0``, so this is a plain concatenation of bytes and of scales, and one
+    GEMV launch then serves all of them."""
+    K = int(weights[0][2][1])
+    if any(int(w[2][1]) != K for w in weights) or K % blocksize:
+        raise ValueError("concat_rows needs equal in_features, divisible by the blocksize")
+    packed = torch.cat([w[0].reshape(-1) for w in weights]).reshape(-1, 1)
+    absmax = torch.cat([w[1].reshape(-1) for w in weights])
+    return packed, absmax, (sum(int(w[2][0]) for w in weights), K)
+
+
 def _quant_data(packed, absmax, shape, blocksize, bias, use_codebook_dequant=True) -> QuantData:
     state = QuantState(absmax, shape, fp4_code().to(packed.device), blocksize)
     return QuantData(packed, state, state.shape, original_lin=None, bias=bias, use_codebook_dequant=use_codebook_dequant)

@@ -12,6 +12,9 @@ numel == last dim, 2-D or 3-D         fused GEMV, bias added after       (:603-6
 numel == last dim, other ranks        ``qlinear``                        (:614-615)
 everything else (batch or seq > 1)    ``qlinear`` = dequant + F.linear   (:616-617)
 ====================================  =========================================
+
+Opt-in extensions (off by default so the table above holds): ``fuse_bias`` folds the post-GEMV bias add into the
+kernel epilogue (bit-identical); ``small_batch_fused`` sends 2..8 activation rows to the fused small-batch kernel.
 """
 from __future__ import annotations
 
@@ -28,7 +31,8 @@ from .functional import dequantize_fp4_codebook_invoke_qtype, dequantize_fp4_qty
 class QuantData:
     def __init__(self, A: torch.Tensor, state, shape: Tuple[int, int], original_lin=None,
                  bias: Optional[torch.Tensor] = None, use_codebook_dequant: Optional[bool] = True,
-                 allow_reduced_precision_linear: Optional[bool] = False, fuse_bias: bool = True):
+                 allow_reduced_precision_linear: Optional[bool] = False, fuse_bias: bool = True,
+                 small_batch_fused: bool = False):
         self.use_codebook_dequant = use_codebook_dequant
         self.A = A
         self.absmax = state.absmax.float()
@@ -45,6 +49,9 @@ class QuantData:
         self.numel = prod(shape)
         # fuse the post-GEMV `out += bias` into the kernel epilogue (bit-identical, one launch fewer)
         self.fuse_bias = fuse_bias
+        # opt-in: 2..8 activation rows go to the fused small-batch kernel instead of dequant + GEMM (the reference
+        # always dequantises for batch > 1, :616-617; same result up to rounding, ~5x less HBM traffic)
+        self.small_batch_fused = small_batch_fused
         if allow_reduced_precision_linear:
             self.qlinear = self._qlinear_low_precision_codebook if use_codebook_dequant else self._qlinear_low_precision_normal
         else:
@@ -99,6 +106,10 @@ class QuantData:
         K = A.shape[-1]
         single_token = total == K
         if not single_token or K % self.blocksize != 0 or A.ndim not in (2, 3):
+            if (self.small_batch_fused and 2 <= total // K <= 8 and K % self.blocksize == 0 and K % 32 == 0 and K <= 4096
+                    and A.dtype in (torch.float16, torch.bfloat16)):
+                return ext.gemm_small_fp4(A.contiguous(), self.A.t(), self.absmax, self.blocksize,
+                                          list(self.quant_state.shape), self.bias)
             return self.qlinear(A)
         if not A.is_contiguous():
             A = A.contiguous()
