@@ -139,3 +139,45 @@ def test_state_dict_and_device_move():
     fp4.to(dev())
     assert torch.equal(fp4(x), y)
     assert "TorchFP4Linear(in_features=256, out_features=128, bias=True" in repr(fp4)
+
+
+def test_bitsandbytes_format_roundtrip(tmp_path):
+    """TorchFP4Linear -> bitsandbytes 4-bit state-dict layout -> safetensors -> TorchFP4Linear, bit-identical outputs."""
+    P = pkg()
+    torch.manual_seed(3)
+
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = nn.Linear(256, 512)
+            self.norm = nn.LayerNorm(512)
+            self.b = nn.Linear(512, 128, bias=False)
+
+        def forward(self, x):
+            return self.b(self.norm(self.a(x)))
+
+    net = P.recursively_replace_with_fp4_linear(Net().to(dev()), device=dev())
+    x = torch.randn(1, 256, device=dev(), dtype=torch.bfloat16)
+    xb = torch.randn(4, 256, device=dev(), dtype=torch.bfloat16)
+    net.norm.to(torch.bfloat16)
+    y, yb = net(x), net(xb)
+    entries = P.fp4_linear_to_bnb_state(net.a, "a.")
+    assert set(entries) == {"a.weight", "a.weight.absmax", "a.weight.quant_map", "a.weight.quant_state.bitsandbytes__fp4", "a.bias"}
+    assert entries["a.weight"].dtype == torch.uint8 and entries["a.weight"].shape == (512 * 256 // 2, 1)
+    import json
+
+    meta = json.loads(bytes(entries["a.weight.quant_state.bitsandbytes__fp4"].tolist()).decode())
+    assert meta["quant_type"] == "fp4" and meta["blocksize"] == 64 and meta["shape"] == [512, 256]
+    path = str(tmp_path / "model.safetensors")
+    P.save_fp4_model(net, path)
+    fresh = Net().to(dev())
+    fresh.norm.to(torch.bfloat16)
+    fresh = P.load_fp4_layers(fresh, path, device=dev())
+    assert isinstance(fresh.a, P.TorchFP4Linear) and isinstance(fresh.b, P.TorchFP4Linear)
+    assert torch.equal(fresh(x), y) and torch.equal(fresh(xb), yb)
+    with pytest.raises(KeyError):
+        P.fp4_linear_from_bnb_state({"w.weight": entries["a.weight"]}, "w.")
+    bad = dict(entries)
+    bad["a.weight.nested_absmax"] = torch.zeros(1)
+    with pytest.raises(ValueError, match="nested"):
+        P.fp4_linear_from_bnb_state(bad, "a.")

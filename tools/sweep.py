@@ -74,3 +74,12 @@ if what in ("gemv", "all"):
     cold = capture(lambda: [hipabi.gemv(x, packed[i % R], absmax[i % R], M, K, 64) for i in range(R * 2)])
     c, cm = timeit(cold, R * 2)
     print(f"gemv f32 {M}x{K} cold {c:6.2f} us = {(n // 2 + 4 * (n // 64) + (K + M) * 4) / c / 1e3:6.0f} GB/s", flush=True)
+
+if what in ("quant", "all"):
+    for dt, name, isz in ((torch.bfloat16, "bf16", 2), (torch.float16, "f16", 2), (torch.float32, "f32", 4)):
+        RW = 16
+        ws = [torch.randn(n, device=dev).to(dt) for _ in range(RW)]
+        nbytes = n * isz + n // 2 + 4 * (n // 64)
+        cold = capture(lambda: [hipabi.quantize(ws[i % RW], 64) for i in range(RW * 2)])
+        c, cm = timeit(cold, RW * 2)
+        print(f"quantize {name} {M}x{K} bs64 cold {c:7.2f} us (min {cm:7.2f}) = {nbytes / c / 1e3:7.0f} GB/s", flush=True)

@@ -25,6 +25,7 @@ from .functional import (
 from .linear import TorchFP4Linear
 from .nn import Linear4bit, LinearFP4, Params4bit, QuantState
 from .quant_data import QuantData
+from .serialization import fp4_linear_from_bnb_state, fp4_linear_to_bnb_state, load_fp4_layers, save_fp4_model
 from .surgery import (
     check_if_name_contained_in_list,
     recursively_replace_with_fp4_linear,
@@ -51,5 +52,9 @@ __all__ = [
     "Linear4bit",
     "Params4bit",
     "QuantState",
+    "fp4_linear_to_bnb_state",
+    "fp4_linear_from_bnb_state",
+    "save_fp4_model",
+    "load_fp4_layers",
 ]
 __version__ = "0.1.0"

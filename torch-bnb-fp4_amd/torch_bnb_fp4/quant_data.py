@@ -52,6 +52,9 @@ class QuantData:
         # opt-in: 2..8 activation rows go to the fused small-batch kernel instead of dequant + GEMM (the reference
         # always dequantises for batch > 1, :616-617; same result up to rounding, ~5x less HBM traffic)
         self.small_batch_fused = small_batch_fused
+        # per-call constants of the decode path, built once (224 calls per token in a 7B model)
+        self._B_t = A.t()
+        self._shape_list = [int(shape[0]), int(shape[1])]
         if allow_reduced_precision_linear:
             self.qlinear = self._qlinear_low_precision_codebook if use_codebook_dequant else self._qlinear_low_precision_normal
         else:
@@ -81,8 +84,11 @@ class QuantData:
     # -- fused paths -----------------------------------------------------------------------------
     def _qgemv(self, A: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
         # the reference hands the packed [numel/2, 1] tensor over transposed (:486); it stays contiguous
-        return gemm_4bit_inference_qtype(A=A, B=self.A.t(), absmax=self.absmax, code=self.code, blocksize=self.blocksize,
-                                         dtype=self.qtype, Bshape=self.quant_state.shape, bias=bias)
+        if self._B_t.data_ptr() != self.A.data_ptr():  # the packed tensor was replaced (e.g. a device move)
+            self._B_t = self.A.t()
+        if bias is not None:
+            return ext.gemv_fp4_bias(A, self._B_t, self.absmax, self.code, self.blocksize, self.qtype, self._shape_list, bias)
+        return ext.gemv_fp4(A, self._B_t, self.absmax, self.code, self.blocksize, self.qtype, self._shape_list)
 
     def _qlinear_low_precision_normal(self, A: torch.Tensor) -> torch.Tensor:
         if self.bias is None:
