@@ -180,13 +180,19 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         sys.exit(f"--gpus {args.gpus} needs torchrun with --nproc-per-node {args.gpus} (WORLD_SIZE={world})")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    # one rank per GPU; FP4_BENCH_BACKEND=gloo lets the N > 1 code path be rehearsed on a box with fewer GPUs
+    backend = os.environ.get("FP4_BENCH_BACKEND", "nccl")
+    local_dev = local % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     lib = Lib()
     R, GR = args.matrices, args.gemv_reps
@@ -280,7 +286,7 @@ def main():
             extra["device_copy_gbps"] = round(2 * src.numel() / us / 1e3, 1)
             del src, dst
 
-    times = torch.tensor([wall, dq_total_s, gv_total_s], dtype=torch.float64, device=dev)
+    times = torch.tensor([wall, dq_total_s, gv_total_s], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(times, op=dist.ReduceOp.MAX)
     wall, dq_total_s, gv_total_s = times.tolist()
