@@ -35,7 +35,7 @@ def lib():
         l.fp4_hip_abi_version.restype = i32
         l.fp4_hip_last_error.restype = ctypes.c_char_p
         l.fp4_hip_code_table.argtypes = [i32, vp]
-        l.fp4_hip_dequantize_blockwise.argtypes = [vp, vp, vp, i32, i64, i32, i32, vp]
+        l.fp4_hip_dequantize_blockwise.argtypes = [vp, vp, vp, i32, i64, i32, i32, i32, vp]
         l.fp4_hip_gemv.argtypes = [vp, vp, vp, vp, vp, i64, i64, i32, i32, vp]
         l.fp4_hip_gemv_partial.argtypes = [vp, vp, vp, vp, i64, i64, i32, i32, vp]
         l.fp4_hip_gemm_small.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, i32, i32, vp]
@@ -61,11 +61,14 @@ def _ptr(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
+AUTO, KEEP_CACHED, STREAM = 0, 1, 2
+
+
 def dequantize(packed: torch.Tensor, absmax: torch.Tensor, blocksize: int, n: int, dtype: torch.dtype, table: int = TABLE_CODEBOOK,
-               out: torch.Tensor | None = None) -> torch.Tensor:
+               out: torch.Tensor | None = None, flags: int = AUTO) -> torch.Tensor:
     if out is None:
         out = torch.empty(n, dtype=dtype, device=packed.device)
-    rc = lib().fp4_hip_dequantize_blockwise(_ptr(packed), _ptr(absmax), _ptr(out), blocksize, n, DT[dtype], table, _stream())
+    rc = lib().fp4_hip_dequantize_blockwise(_ptr(packed), _ptr(absmax), _ptr(out), blocksize, n, DT[dtype], table, flags, _stream())
     assert rc == OK, (rc, last_error())
     return out
 

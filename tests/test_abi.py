@@ -24,7 +24,7 @@ def test_header_symbols_are_exported():
 
 def test_abi_version_and_tables():
     l = hipabi.lib()
-    assert l.fp4_hip_abi_version() == 1
+    assert l.fp4_hip_abi_version() == 2
     for which, tab in ((hipabi.TABLE_CODEBOOK, o.CODEBOOK_TABLE), (hipabi.TABLE_TREE, o.TREE_TABLE)):
         out = np.zeros(16, np.float32)
         assert l.fp4_hip_code_table(which, out.ctypes.data_as(ctypes.c_void_p)) == hipabi.OK
@@ -35,13 +35,14 @@ def test_abi_version_and_tables():
 def test_argument_validation_without_gpu():
     l = hipabi.lib()
     one = ctypes.c_void_p(16)  # never dereferenced: validation fails first
-    assert l.fp4_hip_dequantize_blockwise(one, one, one, 64, -1, hipabi.F16, 0, None) == hipabi.ERR_INVALID
-    assert l.fp4_hip_dequantize_blockwise(one, one, one, 63, 128, hipabi.F16, 0, None) == hipabi.ERR_INVALID
+    assert l.fp4_hip_dequantize_blockwise(one, one, one, 64, -1, hipabi.F16, 0, 0, None) == hipabi.ERR_INVALID
+    assert l.fp4_hip_dequantize_blockwise(one, one, one, 63, 128, hipabi.F16, 0, 0, None) == hipabi.ERR_INVALID
     assert "blocksize" in hipabi.last_error()
-    assert l.fp4_hip_dequantize_blockwise(one, one, one, 64, 128, hipabi.F16, 5, None) == hipabi.ERR_INVALID
-    assert l.fp4_hip_dequantize_blockwise(None, one, one, 64, 128, hipabi.F16, 0, None) == hipabi.ERR_INVALID
-    assert l.fp4_hip_dequantize_blockwise(one, one, one, 64, 128, 9, 0, None) == hipabi.ERR_UNSUPPORTED
-    assert l.fp4_hip_dequantize_blockwise(None, None, None, 64, 0, hipabi.F16, 0, None) == hipabi.OK  # empty input
+    assert l.fp4_hip_dequantize_blockwise(one, one, one, 64, 128, hipabi.F16, 5, 0, None) == hipabi.ERR_INVALID
+    assert l.fp4_hip_dequantize_blockwise(None, one, one, 64, 128, hipabi.F16, 0, 0, None) == hipabi.ERR_INVALID
+    assert l.fp4_hip_dequantize_blockwise(one, one, one, 64, 128, 9, 0, 0, None) == hipabi.ERR_UNSUPPORTED
+    assert l.fp4_hip_dequantize_blockwise(None, None, None, 64, 0, hipabi.F16, 0, 0, None) == hipabi.OK  # empty input
+    assert l.fp4_hip_dequantize_blockwise(one, one, one, 64, 128, hipabi.F16, 0, 7, None) == hipabi.ERR_INVALID  # bad flags
     assert l.fp4_hip_gemv(one, one, one, None, one, 4, 63, 64, hipabi.BF16, None) == hipabi.ERR_INVALID  # odd K
     assert l.fp4_hip_gemv(one, one, one, None, one, 4, 64, 64, 9, None) == hipabi.ERR_UNSUPPORTED
     assert l.fp4_hip_gemv(None, None, None, None, None, 0, 64, 64, hipabi.BF16, None) == hipabi.OK  # M == 0

@@ -146,3 +146,15 @@ def test_torch_ext_ops_and_stream_semantics():
         pkg.dequantize_fp4(to_dev(np.zeros((64, 2), np.uint8))[:, 0], absmax, 64, 8, 8, torch.float16)
     with pytest.raises(RuntimeError, match="uint8"):
         pkg.dequantize_fp4(absmax, absmax, 64, 1, 1, torch.float16)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_cache_policy_flags_do_not_change_bits(dtype):
+    n = 4096 * 4096
+    rng = np.random.default_rng(21)
+    packed = rng.integers(0, 256, n // 2, dtype=np.uint8)
+    am = (rng.random(n // 64, dtype=np.float32) * 0.1 + 0.01).astype(np.float32)
+    want = np_bits(c_oracle.dequantize(packed, am, 64, n, NPDT[dtype]))
+    P, A = to_dev(packed), to_dev(am)
+    for flags in (hipabi.AUTO, hipabi.KEEP_CACHED, hipabi.STREAM):
+        assert np.array_equal(bits(hipabi.dequantize(P, A, 64, n, dtype, flags=flags)), want), flags

@@ -71,8 +71,8 @@ def test_dispatch_table(fake, dtype):
     qd, wq, lin = make_quant_data(M, K)
     tol = {torch.float32: 1e-5, torch.bfloat16: 6e-2, torch.float16: 1e-2}[dtype]
     gen = torch.Generator().manual_seed(1)
-    cases = [((1, K), "gemv_fp4_bias", (1, M)), ((1, 1, K), "gemv_fp4_bias", (1, 1, M)), ((2, K), "dequantize_fp4_codebook", (2, M)),
-             ((1, 5, K), "dequantize_fp4_codebook", (1, 5, M)), ((1, 1, 1, K), "dequantize_fp4_codebook", (1, 1, 1, M))]
+    cases = [((1, K), "gemv_fp4_bias", (1, M)), ((1, 1, K), "gemv_fp4_bias", (1, 1, M)), ((2, K), "qlinear_codebook_bias", (2, M)),
+             ((1, 5, K), "qlinear_codebook_bias", (1, 5, M)), ((1, 1, 1, K), "qlinear_codebook_bias", (1, 1, 1, M))]
     for shape, want_call, want_shape in cases:
         fake.calls.clear()
         x = torch.randn(*shape, generator=gen).to(dtype)
@@ -97,7 +97,7 @@ def test_dispatch_non_multiple_of_blocksize_and_non_contiguous(fake):
     state = pkg.QuantState(torch.from_numpy(am), (M, K), torch.from_numpy(o.TREE_TABLE.copy()), 64)  # layer claims bs 64
     qd = pkg.QuantData(torch.from_numpy(packed).view(-1, 1), state, state.shape, original_lin=nn.Linear(K, M, bias=False))
     qd.forward(torch.randn(1, K))
-    assert fake.calls == ["dequantize_fp4_codebook"]
+    assert fake.calls == ["qlinear_codebook"]  # = dequant (codebook table) + linear in one extension call
     # non-contiguous single token -> made contiguous, then GEMV (:596-597)
     qd2, wq, lin = make_quant_data(64, 128, bias=False)
     fake.calls.clear()
@@ -114,7 +114,10 @@ def test_unfused_bias_and_tree_and_low_precision_paths(fake):
     assert fake.calls == ["gemv_fp4"] and torch.allclose(y, x @ wq.t() + lin.bias, atol=1e-4)
     fake.calls.clear()
     qd.forward(torch.randn(3, 128))
-    assert fake.calls == ["dequantize_fp4"]  # tree dequant (:456-469)
+    assert fake.calls == ["qlinear_bias"]  # tree dequant (:456-469) + linear
+    fake.calls.clear()
+    qd.dequantize()
+    assert fake.calls == ["dequantize_fp4"]  # the stand-alone dequantize() of the reference is still there
     for codebook, name in ((True, "qlinear_codebook_bias"), (False, "qlinear_bias")):
         qd2, _, _ = make_quant_data(32, 128, allow_reduced_precision_linear=True, use_codebook_dequant=codebook)
         fake.calls.clear()
@@ -136,7 +139,7 @@ def test_small_batch_opt_in(fake):
     assert (y.float() - ref).abs().max() <= 6e-2 * max(1.0, ref.abs().max().item())
     fake.calls.clear()
     qd.forward(torch.randn(9, 128).to(torch.bfloat16))  # > 8 rows: the reference path
-    assert fake.calls == ["dequantize_fp4_codebook"]
+    assert fake.calls == ["qlinear_codebook_bias"]
     fake.calls.clear()
     qd.forward(torch.randn(1, 128).to(torch.bfloat16))  # single token is still the GEMV
     assert fake.calls == ["gemv_fp4_bias"]

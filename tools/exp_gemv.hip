@@ -171,6 +171,8 @@ int main(int argc, char **argv) {
         {"lds r1 w16 u2", 1 | (16 << 8) | (2 << 16)}, {"lds r2 w4 u2", 2 | (4 << 8) | (2 << 16)},
         {"regx it1", (1 << 24) | 1},                  {"regx it2", (1 << 24) | 2},
         {"regx it4", (1 << 24) | 4},                  {"regx it8", (1 << 24) | 8},
+        {"regx ks2 it1", (1 << 24) | (2 << 8) | 1}, {"regx ks2 it2", (1 << 24) | (2 << 8) | 2}, {"regx ks2 it4", (1 << 24) | (2 << 8) | 4},
+        {"regx ks1 it1", (1 << 24) | (1 << 8) | 1}, {"regx ks1 it2", (1 << 24) | (1 << 8) | 2},
         {"default heuristic", -1},
     };
     for (auto &v : variants) {

@@ -45,13 +45,13 @@ if what in ("dequant", "all"):
     for dt, name, isz in ((torch.bfloat16, "bf16", 2), (torch.float16, "f16", 2), (torch.float32, "f32", 4)):
         outs = [torch.empty(n, dtype=dt, device=dev) for _ in range(min(R, 32))]
         nbytes = n // 2 + 4 * (n // 64) + n * isz
-        for variant in (1, 2, 4, 8, 16, 1 | 256, 2 | 256, 4 | 256, 8 | 256, 16 | 256):
+        for variant in (-1, 1, 2, 4, 8, 16, 1 | 256, 2 | 256, 4 | 256, 8 | 256, 16 | 256):
             hipabi.set_variant("dequant", variant)
             cold = capture(lambda: [hipabi.dequantize(packed[i], absmax[i], 64, n, dt, out=outs[i % len(outs)]) for i in range(R)])
             hot = capture(lambda: [hipabi.dequantize(packed[0], absmax[0], 64, n, dt, out=outs[0]) for i in range(R)])
             c, cm = timeit(cold, R)
             h, hm = timeit(hot, R)
-            print(f"dequant {name} {M}x{K} loads={variant & 255:2d} nt={variant >> 8} cold {c:7.2f} us (min {cm:7.2f}) = {nbytes / c / 1e3:7.0f} GB/s   hot {h:7.2f} us = {nbytes / h / 1e3:7.0f} GB/s", flush=True)
+            print(f"dequant {name} {M}x{K} loads={variant & 255 if variant >= 0 else -1:2d} nt={variant >> 8 if variant >= 0 else -1} cold {c:7.2f} us (min {cm:7.2f}) = {nbytes / c / 1e3:7.0f} GB/s   hot {h:7.2f} us = {nbytes / h / 1e3:7.0f} GB/s", flush=True)
         del outs
     hipabi.set_variant("dequant", -1)
 

@@ -453,7 +453,7 @@ __global__ __launch_bounds__(256) void gemv_generic_kernel(const void *__restric
     }
 }
 
-int g_gemv_variant = -1;  // LDS geometry: ROWS | WAVES << 8 | UNROLL << 16; register-x geometry: 1 << 24 | ITERS; -1 = heuristic
+int g_gemv_variant = -1;  // LDS geometry: ROWS | WAVES << 8 | UNROLL << 16; register-x geometry: 1 << 24 | KSPLIT_override << 8 | ITERS; -1 = heuristic
 
 constexpr int kMaxLdsBytes = 160 * 1024 - 256;
 
@@ -677,38 +677,35 @@ int launch_regx(const void *x, const uint8_t *W, const float *absmax, const void
     return FP4_OK;
 }
 
-// K decides the band split and the x-slice depth; ITERS (row pairs per group) is the tunable.
+// K decides the band split and the x-slice depth; ITERS (row pairs per group) is the tunable.  `ks_override`
+// (sweeps only) forces KSPLIT; G follows from ceil(C / (32 * KSPLIT)).
 template <int DT>
-int dispatch_regx(int iters, const void *x, const uint8_t *W, const float *absmax, const void *bias, void *out, int M, int K,
-                  int bs_shift, int out_f32, hipStream_t stream) {
+int dispatch_regx(int iters, int ks_override, const void *x, const uint8_t *W, const float *absmax, const void *bias, void *out,
+                  int M, int K, int bs_shift, int out_f32, hipStream_t stream) {
     const int C = K >> 5;
+    int ks = C <= 32 ? 1 : (C <= 64 ? 2 : 4);
+    if (ks_override == 1 || ks_override == 2 || ks_override == 4) ks = ks_override;
+    const int need = (C + 32 * ks - 1) / (32 * ks);
+    const int g = need <= 1 ? 1 : (need <= 2 ? 2 : (need <= 4 ? 4 : 0));
+    if (g == 0) return -1;  // the x slice no longer fits the register budget; use the LDS geometry
+    if (g == 2 && iters > 4) iters = 4;
+    if (g == 4 && iters > 2) iters = 2;
 #define FP4_RX(KS, GG, IT) return launch_regx<DT, KS, GG, IT>(x, W, absmax, bias, out, M, K, bs_shift, out_f32, stream)
-#define FP4_RX_IT(KS, GG)          \
-    switch (iters) {               \
-        case 1: FP4_RX(KS, GG, 1); \
-        case 2: FP4_RX(KS, GG, 2); \
-        case 4: FP4_RX(KS, GG, 4); \
-        case 8: FP4_RX(KS, GG, 8); \
-        default: break;            \
+#define FP4_RX_IT(KS, GG)              \
+    if (ks == KS && g == GG) {         \
+        switch (iters) {               \
+            case 1: FP4_RX(KS, GG, 1); \
+            case 2: FP4_RX(KS, GG, 2); \
+            case 4: FP4_RX(KS, GG, 4); \
+            case 8: FP4_RX(KS, GG, 8); \
+            default: break;            \
+        }                              \
     }
-    if (C <= 32) {
-        FP4_RX_IT(1, 1)
-    } else if (C <= 64) {
-        FP4_RX_IT(2, 1)
-    } else if (C <= 128) {
-        FP4_RX_IT(4, 1)
-    } else if (C <= 256) {
-        if (iters > 4) iters = 4;
-        FP4_RX_IT(4, 2)
-    } else if (C <= 512) {
-        if (iters > 2) iters = 2;
-        FP4_RX_IT(4, 4)
-    } else {
-        return -1;  // K > 16384: the x slice no longer fits the register budget; use the LDS geometry
-    }
+    FP4_RX_IT(1, 1) FP4_RX_IT(1, 2) FP4_RX_IT(1, 4) FP4_RX_IT(2, 1) FP4_RX_IT(2, 2) FP4_RX_IT(2, 4) FP4_RX_IT(4, 1) FP4_RX_IT(4, 2)
+    FP4_RX_IT(4, 4)
 #undef FP4_RX_IT
 #undef FP4_RX
-    set_error("fp4_hip_gemv: unknown regx iteration count %d", iters);
+    set_error("fp4_hip_gemv: unknown regx geometry (iters %d, ksplit %d, g %d)", iters, ks, g);
     return FP4_ERR_INVALID_ARGUMENT;
 }
 
@@ -774,10 +771,11 @@ int gemv_entry(const void *x, const uint8_t *packed, const float *absmax, const 
         int variant = g_gemv_variant >= 0 ? g_gemv_variant : default_variant16((int)M, (int)K);
         rc = -1;
         if (variant & kRegxFlag) {
-            const int iters = variant & 0xFF;
-            rc = dtype == FP4_DTYPE_F16
-                     ? dispatch_regx<FP4_DTYPE_F16>(iters, x, packed, absmax, bias, out, (int)M, (int)K, bs_shift, out_f32, s)
-                     : dispatch_regx<FP4_DTYPE_BF16>(iters, x, packed, absmax, bias, out, (int)M, (int)K, bs_shift, out_f32, s);
+            const int iters = variant & 0xFF, ks_override = (variant >> 8) & 0xF;
+            rc = dtype == FP4_DTYPE_F16 ? dispatch_regx<FP4_DTYPE_F16>(iters, ks_override, x, packed, absmax, bias, out, (int)M,
+                                                                       (int)K, bs_shift, out_f32, s)
+                                        : dispatch_regx<FP4_DTYPE_BF16>(iters, ks_override, x, packed, absmax, bias, out, (int)M,
+                                                                        (int)K, bs_shift, out_f32, s);
             if (rc == -1) variant = 1 | (8 << 8) | (2 << 16);  // K too large for register-resident x
         }
         if (rc == -1)

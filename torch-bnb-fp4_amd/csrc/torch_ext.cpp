@@ -71,7 +71,7 @@ void *current_stream(const torch::Tensor &t) { return c10::hip::getCurrentHIPStr
 
 // dequant of the first n elements of `out` (out is [M,N], n <= M*N)
 void dequant_into(const torch::Tensor &A, const torch::Tensor &absmax, torch::Tensor &out, int64_t blocksize, int64_t n,
-                  int table) {
+                  int table, int flags = FP4_DEQUANT_AUTO) {
     // reference: TORCH_CHECKs of csrc/dequant_fp4_optimized.cu:183-187,210-213
     TORCH_CHECK(A.dtype() == torch::kUInt8, "A must be uint8");
     TORCH_CHECK(absmax.dtype() == torch::kFloat32, "absmax must be float32");
@@ -87,7 +87,7 @@ void dequant_into(const torch::Tensor &A, const torch::Tensor &absmax, torch::Te
     const int dt = to_fp4_dtype(out.scalar_type(), "dequantize");
     c10::DeviceGuard guard(A.device());
     check_status(fp4_hip_dequantize_blockwise(A.data_ptr<uint8_t>(), absmax.data_ptr<float>(), out.data_ptr(), (int)blocksize,
-                                              n, dt, table, current_stream(A)));
+                                              n, dt, table, flags, current_stream(A)));
 }
 
 torch::Tensor dequantize_fp4(torch::Tensor A, torch::Tensor absmax, int blocksize, int M, int N, ScalarTypeEnum o_type) {
@@ -113,7 +113,8 @@ torch::Tensor qlinear_impl(const torch::Tensor &A_in, const torch::Tensor &A, co
     check_gpu_contiguous(A, "A");
     check_gpu_contiguous(absmax, "absmax");
     torch::Tensor weight = torch::empty({M, N}, A_in.options());
-    dequant_into(A, absmax, weight, blocksize, int64_t(M) * N, table);
+    // the GEMM below reads the weight straight back: keep it in L2 / Infinity Cache (plain stores)
+    dequant_into(A, absmax, weight, blocksize, int64_t(M) * N, table, FP4_DEQUANT_KEEP_CACHED);
     return bias.has_value() ? at::linear(A_in, weight, *bias) : at::linear(A_in, weight);
 }
 

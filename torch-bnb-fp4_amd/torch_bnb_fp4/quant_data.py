@@ -79,7 +79,12 @@ class QuantData:
         return dequantize_fp4_qtype(self.A, self.absmax, self.blocksize, self.M, self.N, self.qtype)
 
     def _dequant_linear(self, A: torch.Tensor) -> torch.Tensor:
-        return torch.nn.functional.linear(A, self.dequantize(), self.bias)
+        # Same maths as the reference's F.linear(A, self.dequantize(), self.bias) (:423-436), done by the
+        # extension's qlinear* ops in one call: the dequant there keeps its output cache-resident for the GEMM
+        # (plain stores; standalone dequantize() streams it out non-temporally), and one Python round trip is saved.
+        if A.dtype != self.o_type:
+            return torch.nn.functional.linear(A, self.dequantize(), self.bias)
+        return self._qlinear_low_precision_codebook(A) if self.use_codebook_dequant else self._qlinear_low_precision_normal(A)
 
     # -- fused paths -----------------------------------------------------------------------------
     def _qgemv(self, A: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
