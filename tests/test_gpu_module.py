@@ -181,3 +181,38 @@ def test_bitsandbytes_format_roundtrip(tmp_path):
     bad["a.weight.nested_absmax"] = torch.zeros(1)
     with pytest.raises(ValueError, match="nested"):
         P.fp4_linear_from_bnb_state(bad, "a.")
+
+
+def test_hip_graph_capture_and_replay_of_the_linear_shell():
+    """Every op on the path is capturable (no allocation in the C ABI, current-stream launches): a decode step
+    captured once replays correctly on new inputs (the reference's legacy-stream launches could not be captured)."""
+    P = pkg()
+    torch.manual_seed(5)
+    lin1, lin2 = nn.Linear(512, 1024).to(dev()), nn.Linear(1024, 256).to(dev())
+    f1 = P.TorchFP4Linear(P.swap_linear_with_bnb_linear(lin1).to(dev()))
+    f2 = P.TorchFP4Linear(P.swap_linear_with_bnb_linear(lin2).to(dev()))
+    static_x = torch.randn(1, 512, device=dev(), dtype=torch.bfloat16)
+    static_xb = torch.randn(4, 512, device=dev(), dtype=torch.bfloat16)
+
+    def step(x):
+        return f2(torch.nn.functional.gelu(f1(x)))
+
+    with torch.inference_mode():
+        eager = step(static_x).clone()
+        eager_b = step(static_xb).clone()
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            g = torch.cuda.CUDAGraph()
+            step(static_x), step(static_xb)
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g):
+                out, out_b = step(static_x), step(static_xb)  # GEMV path and dequant+GEMM path
+        torch.cuda.synchronize()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, eager) and torch.equal(out_b, eager_b)
+        new_x = torch.randn(1, 512, device=dev(), dtype=torch.bfloat16)
+        static_x.copy_(new_x)
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, step(new_x))
