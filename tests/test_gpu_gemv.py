@@ -219,3 +219,22 @@ def test_small_batch_fused_gemm(dtype, B, M, K):
         scale = wabs @ np.abs(xv) + np.abs(bv)
         err = np.abs(y[b].float().cpu().numpy() - exact)
         assert (err <= HALF_ULP[dtype] * 1.01 * np.abs(exact) + 1e-5 * scale + 1e-30).all(), (b, err.max())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_unaligned_operands_take_the_generic_path(dtype):
+    M, K = 48, 1024
+    packed, am, x = make_case(M, K, seed=123)
+    x_full = torch_values(np.concatenate([[0.0], x]), dtype)
+    x_t = x_full[1:]  # element offset: not 16-byte aligned
+    p_full = to_dev(np.concatenate([np.zeros(1, np.uint8), packed]))
+    y = hipabi.gemv(x_t, p_full[1:], to_dev(am), M, K, 64)
+    check(y, x_t, packed, am, M, K, 64, dtype)
+
+
+def test_degenerate_sizes():
+    P, A = torch.zeros(64, dtype=torch.uint8, device=dev()), torch.ones(2, device=dev())
+    x = torch.ones(64, dtype=torch.bfloat16, device=dev())
+    assert hipabi.gemv(x, P, A, 0, 64, 64).numel() == 0  # M = 0
+    y = hipabi.gemv(x[:0], P, A, 2, 0, 64)  # K = 0: empty sum
+    assert torch.equal(y.float(), torch.zeros(2, device=dev()))

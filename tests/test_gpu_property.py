@@ -1,0 +1,54 @@
+"""Randomised GPU parity (hypothesis): arbitrary lengths, block sizes, dtypes, tables and pointer offsets for the
+dequant, arbitrary shapes for the GEMV - every draw is checked against the oracle with the same bars as the
+hand-picked cases (bit-exact / half-ulp)."""
+import numpy as np
+import pytest
+import torch
+from hypothesis import HealthCheck, given, settings, strategies as st
+
+import hipabi
+from gpu_util import NPDT, bits, dev, np_bits, to_dev, torch_values
+from oracle import c_oracle, fp4_oracle as o
+
+pytestmark = pytest.mark.gpu
+DT = [torch.float32, torch.float16, torch.bfloat16]
+COMMON = dict(deadline=None, suppress_health_check=list(HealthCheck), derandomize=True)
+
+
+@settings(max_examples=60, **COMMON)
+@given(n=st.integers(1, 300000), bs_log=st.integers(1, 13), odd_bs=st.booleans(), dt=st.sampled_from(DT),
+       table=st.sampled_from([("codebook", hipabi.TABLE_CODEBOOK), ("tree", hipabi.TABLE_TREE)]), off=st.sampled_from([0, 0, 0, 1, 4, 16]),
+       flags=st.sampled_from([0, 1, 2]), seed=st.integers(0, 2**31))
+def test_dequant_any_shape(n, bs_log, odd_bs, dt, table, off, flags, seed):
+    bs = (1 << bs_log) * (3 if odd_bs and bs_log < 10 else 1)  # even, sometimes not a power of two
+    rng = np.random.default_rng(seed)
+    packed = rng.integers(0, 256, (n + 1) // 2 + off, dtype=np.uint8)
+    am = (rng.random(n // 2 + 8, dtype=np.float32) * 2 + 1e-3).astype(np.float32)  # long enough for any index rule
+    want = np_bits(o.dequantize(packed[off:], am, bs, n, NPDT[dt], table[0]))
+    out = hipabi.dequantize(to_dev(packed)[off:], to_dev(am), bs, n, dt, table[1], flags=flags)
+    assert np.array_equal(bits(out), want)
+
+
+@settings(max_examples=40, **COMMON)
+@given(M=st.integers(1, 300), kc=st.integers(1, 96), bs=st.sampled_from([32, 64, 128, 256]), dt=st.sampled_from(DT),
+       bias=st.booleans(), seed=st.integers(0, 2**31))
+def test_gemv_any_shape(M, kc, bs, dt, bias, seed):
+    K = kc * 32
+    rng = np.random.default_rng(seed)
+    w = (rng.standard_normal(M * K) * 0.05).astype(np.float32)
+    if K % bs:
+        bs = 32
+    packed, am = c_oracle.quantize(w, bs)
+    x_t = torch_values(rng.standard_normal(K), dt)
+    b_t = torch_values(rng.standard_normal(M) * 0.1, dt) if bias else None
+    P, A = to_dev(packed), to_dev(am)
+    y = hipabi.gemv(x_t, P, A, M, K, bs, bias=b_t)
+    if bias:  # exact bias semantics: T(T(sum) + bias) for 16-bit, f32 add for f32
+        plain = hipabi.gemv(x_t, P, A, M, K, bs)
+        assert torch.equal(y, plain + b_t)
+        y = plain
+    xv = x_t.float().cpu().numpy().astype(np.float64)
+    exact = c_oracle.gemv_f64(xv, packed, am, M, K, bs)
+    scale = np.abs(o.dequantize_f32(packed, am, bs, M * K).reshape(M, K).astype(np.float64)) @ np.abs(xv)
+    half_ulp = {torch.bfloat16: 2.0**-8, torch.float16: 2.0**-11, torch.float32: 0.0}[dt]
+    assert (np.abs(y.float().cpu().numpy() - exact) <= half_ulp * 1.01 * np.abs(exact) + 1e-5 * scale + 1e-30).all()
