@@ -70,6 +70,16 @@ if what in ("gemv", "all"):
             h, hm = timeit(hot, R * reps)
             print(f"gemv {name} {M}x{K} rows={r} waves={w:2d} unroll={u} cold {c:6.2f} us (min {cm:6.2f}) = {nbytes / c / 1e3:6.0f} GB/s   hot {h:6.2f} us = {nbytes / h / 1e3:6.0f} GB/s", flush=True)
     x = torch.randn(K, device=dev)
+    hipabi.set_variant("gemv", 0)
+    cold = capture(lambda: [hipabi.gemv(x, packed[i % R], absmax[i % R], M, K, 64) for i in range(R * 2)])
+    c, cm = timeit(cold, R * 2)
+    print(f"gemv f32 (LDS-x kernel) {M}x{K} cold {c:6.2f} us = {(n // 2 + 4 * (n // 64) + (K + M) * 4) / c / 1e3:6.0f} GB/s", flush=True)
+    for perm in (0, 1):
+        for it in (1, 2, 4, 8):
+            hipabi.set_variant("gemv", (3 << 24) | (perm << 8) | it)
+            cold = capture(lambda: [hipabi.gemv(x, packed[i % R], absmax[i % R], M, K, 64) for i in range(R * 2)])
+            c, cm = timeit(cold, R * 2)
+            print(f"gemv f32 reg-x perm={perm} iters={it} {M}x{K} cold {c:6.2f} us = {(n // 2 + 4 * (n // 64) + (K + M) * 4) / c / 1e3:6.0f} GB/s", flush=True)
     hipabi.set_variant("gemv", -1)
     cold = capture(lambda: [hipabi.gemv(x, packed[i % R], absmax[i % R], M, K, 64) for i in range(R * 2)])
     c, cm = timeit(cold, R * 2)

@@ -23,7 +23,8 @@
 //    exact x @ dequant(W)^T than the reference's, not bit-identical to it.
 //  * cross-lane sum: DPP row rotations (16 lanes) + ds_swizzle (32) + v_readlane (64); no LDS
 //    scratch, no barrier.
-// f32 activations use the CODE_PARAM f32 table from LDS (bit-faithful table, not the decode path).
+// f32 activations: the same register-x geometry; the fp16 pairs of 12*code are widened by v_fma_mix_f32 against the f32 x
+// (the bit-faithful CODE_PARAM f32 table through LDS stays selectable, and serves K > 8192).
 // A generic wave-per-row kernel covers every other shape (K % 32 != 0, odd block sizes, huge K).
 #include "fp4_common.h"
 
@@ -416,6 +417,164 @@ __global__ __launch_bounds__(WAVES * 64) void gemv32_kernel(const float *__restr
     }
 }
 
+// ---- f32 activations, register-x geometry (same structure as gemv16_regx_kernel) -------------------------------
+// x slice as 32 floats per chunk in VGPRs; weights decoded through the bit-faithful CODE_PARAM f32 table in LDS
+// (16 consecutive dwords: every read is a conflict-free broadcast); (sum x*code) * absmax per chunk, f32 throughout.
+template <int KSPLIT, int G, int ITERS, bool PERM>
+__global__ __launch_bounds__(256) void gemv32_regx_kernel(const float *__restrict__ x, const uint8_t *__restrict__ W,
+                                                          const float *__restrict__ absmax, const float *__restrict__ bias,
+                                                          float *__restrict__ out, int M, int K, int bs_shift) {
+    constexpr int RG = 4 / KSPLIT;
+    constexpr int kRowsPerBlock = 2 * RG * ITERS;
+    __shared__ float s_lut[16];
+    __shared__ float s_part[kRowsPerBlock][KSPLIT];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int kw = wave % KSPLIT, rw = wave / KSPLIT;
+    const int half = lane >> 5, l32 = lane & 31;
+    const int C = K >> 5;
+    const int row_base = blockIdx.x * kRowsPerBlock;
+    const u32x4 *Wv = reinterpret_cast<const u32x4 *>(W);
+    if (tid < 16) s_lut[tid] = lut_entry(FP4_TABLE_CODEBOOK, tid);
+
+    int cidx[G];
+    bool live[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const int c = g * (32 * KSPLIT) + kw * 32 + l32;
+        live[g] = c < C;
+        cidx[g] = live[g] ? c : C - 1;
+    }
+    f32x4 xv[G][8];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) xv[g][q] = reinterpret_cast<const f32x4 *>(x)[cidx[g] * 8 + q];
+    }
+    u32x4 wq[ITERS][G];
+    float am[ITERS][G];
+    int rowi[ITERS];
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int local = 2 * (it * RG + rw) + half;
+        const int row = row_base + local;
+        rowi[it] = local;
+        const int rclamp = row < M ? row : M - 1;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int64_t chunk = int64_t(rclamp) * C + cidx[g];
+            wq[it][g] = __builtin_nontemporal_load(Wv + chunk);
+            const float a = absmax[(chunk << 5) >> bs_shift];
+            am[it][g] = live[g] ? a : 0.0f;
+        }
+    }
+    __syncthreads();  // LUT visible
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        float p = 0.0f;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            float s0 = 0.0f, s1 = 0.0f;
+            if constexpr (PERM) {
+                // table-free decode (see decode8): fp16 pairs of 12*code, widened by v_fma_mix against the f32 x
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    uint32_t P[4];
+                    decode8<FP4_DTYPE_F16>(wq[it][g][j], P);
+                    const f32x4 xa = xv[g][2 * j], xb = xv[g][2 * j + 1];  // x0..x3, x4..x7 of this dword
+                    const f16x2 p0 = __builtin_bit_cast(f16x2, P[0]), p1 = __builtin_bit_cast(f16x2, P[1]);
+                    const f16x2 p2 = __builtin_bit_cast(f16x2, P[2]), p3 = __builtin_bit_cast(f16x2, P[3]);
+                    s0 = __builtin_fmaf(float(p0.x), xa.x, s0);  // e0
+                    s1 = __builtin_fmaf(float(p2.x), xa.y, s1);  // e1
+                    s0 = __builtin_fmaf(float(p0.y), xa.z, s0);  // e2
+                    s1 = __builtin_fmaf(float(p2.y), xa.w, s1);  // e3
+                    s0 = __builtin_fmaf(float(p1.x), xb.x, s0);  // e4
+                    s1 = __builtin_fmaf(float(p3.x), xb.y, s1);  // e5
+                    s0 = __builtin_fmaf(float(p1.y), xb.z, s0);  // e6
+                    s1 = __builtin_fmaf(float(p3.y), xb.w, s1);  // e7
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {  // weights 4q..4q+3 of the chunk = bytes 2q, 2q+1
+                    const uint32_t h = (wq[it][g][q >> 1] >> (16 * (q & 1))) & 0xFFFFu;
+                    s0 = __builtin_fmaf(s_lut[(h >> 4) & 15u], xv[g][q].x, s0);
+                    s1 = __builtin_fmaf(s_lut[h & 15u], xv[g][q].y, s1);
+                    s0 = __builtin_fmaf(s_lut[(h >> 12) & 15u], xv[g][q].z, s0);
+                    s1 = __builtin_fmaf(s_lut[(h >> 8) & 15u], xv[g][q].w, s1);
+                }
+            }
+            p = __builtin_fmaf(s0 + s1, am[it][g] * (PERM ? (1.0f / 12.0f) : 1.0f), p);
+        }
+        p = dpp_add<0x128>(p);
+        p = dpp_add<0x124>(p);
+        p = dpp_add<0x122>(p);
+        p = dpp_add<0x121>(p);
+        p += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, p), 0x401F));
+        if constexpr (KSPLIT == 1) {
+            const int row = row_base + rowi[it];
+            if (l32 == 0 && row < M) out[row] = bias ? p + bias[row] : p;
+        } else {
+            if (l32 == 0) s_part[rowi[it]][kw] = p;
+        }
+    }
+    if constexpr (KSPLIT > 1) {
+        __syncthreads();
+        if (tid < kRowsPerBlock) {
+            float t = 0.0f;
+#pragma unroll
+            for (int k = 0; k < KSPLIT; ++k) t += s_part[tid][k];
+            const int row = row_base + tid;
+            if (row < M) out[row] = bias ? t + bias[row] : t;
+        }
+    }
+}
+
+template <int KSPLIT, int G, int ITERS, bool PERM>
+int launch32_regx(const void *x, const uint8_t *W, const float *absmax, const void *bias, void *out, int M, int K, int bs_shift,
+                  hipStream_t stream) {
+    constexpr int rows_per_block = 2 * (4 / KSPLIT) * ITERS;
+    const unsigned blocks = (unsigned)((M + rows_per_block - 1) / rows_per_block);
+    hipLaunchKernelGGL((gemv32_regx_kernel<KSPLIT, G, ITERS, PERM>), dim3(blocks), dim3(256), 0, stream,
+                       reinterpret_cast<const float *>(x), W, absmax, reinterpret_cast<const float *>(bias),
+                       reinterpret_cast<float *>(out), M, K, bs_shift);
+    return FP4_OK;
+}
+
+// returns -1 when K is too deep for a register-resident f32 x slice (K > 8192): use the LDS kernel
+int dispatch32_regx(bool perm, int iters, const void *x, const uint8_t *W, const float *absmax, const void *bias, void *out, int M,
+                    int K, int bs_shift, hipStream_t stream) {
+    const int C = K >> 5;
+    const int ks = C <= 32 ? 1 : (C <= 64 ? 2 : 4);
+    if (iters <= 0) {
+        // the f32 x slice is 128 B per chunk per lane, re-read by every workgroup: amortise it over more rows than
+        // the 16-bit kernel does, as long as >= ~512 workgroups remain
+        // (measured: 4096x4096 5.1 us at 4 row pairs vs 9.3 us at 1; profiles/r01_d_*)
+        iters = 1;
+        while (iters < 4 && M / (2 * (4 / ks) * iters * 2) >= 256) iters *= 2;
+    }
+#define FP4_R32_IT(KS, GG, PERM)                                                                               \
+    switch (iters) {                                                                                           \
+        case 1: return launch32_regx<KS, GG, 1, PERM>(x, W, absmax, bias, out, M, K, bs_shift, stream);        \
+        case 2: return launch32_regx<KS, GG, 2, PERM>(x, W, absmax, bias, out, M, K, bs_shift, stream);        \
+        case 4: return launch32_regx<KS, GG, 4, PERM>(x, W, absmax, bias, out, M, K, bs_shift, stream);        \
+        default: return launch32_regx<KS, GG, 8, PERM>(x, W, absmax, bias, out, M, K, bs_shift, stream);       \
+    }
+#define FP4_R32(KS, GG)          \
+    if (perm) {                  \
+        FP4_R32_IT(KS, GG, true) \
+    } else {                     \
+        FP4_R32_IT(KS, GG, false) \
+    }
+    if (C <= 32) { FP4_R32(1, 1) }
+    if (C <= 64) { FP4_R32(2, 1) }
+    if (C <= 128) { FP4_R32(4, 1) }
+    if (C <= 256) { if (iters > 4) iters = 4; FP4_R32(4, 2) }
+#undef FP4_R32
+#undef FP4_R32_IT
+    return -1;
+}
+
 // ---- generic: any even K, any even blocksize, no alignment assumptions ---------------------------
 template <int DT>
 __global__ __launch_bounds__(256) void gemv_generic_kernel(const void *__restrict__ xv, const uint8_t *__restrict__ W,
@@ -782,6 +941,10 @@ int gemv_entry(const void *x, const uint8_t *packed, const float *absmax, const 
             rc = dtype == FP4_DTYPE_F16
                      ? dispatch16<FP4_DTYPE_F16>(variant, x, packed, absmax, bias, out, (int)M, (int)K, bs_shift, out_f32, s)
                      : dispatch16<FP4_DTYPE_BF16>(variant, x, packed, absmax, bias, out, (int)M, (int)K, bs_shift, out_f32, s);
+    } else if (fast && g_gemv_variant != 0 &&
+               dispatch32_regx(g_gemv_variant < 0 || ((g_gemv_variant >> 8) & 1), g_gemv_variant < 0 ? 0 : (g_gemv_variant & 0xFF), x,
+                               packed, absmax, bias, out, (int)M, (int)K, bs_shift, s) == FP4_OK) {
+        rc = FP4_OK;  // f32 activations, register-x geometry (variant 0 forces the LDS kernel below, for sweeps)
     } else if (fast) {
         auto kern = gemv32_kernel<1, 4>;
         const size_t lds = size_t(K) * 4;
