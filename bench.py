@@ -78,7 +78,8 @@ def capture(fn):
     fn()
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
+    # thread_local: helper threads of the process (e.g. the RCCL watchdog at N > 1) must not invalidate the capture
+    with torch.cuda.graph(g, capture_error_mode="thread_local"):
         fn()
     torch.cuda.synchronize()
     return g.replay

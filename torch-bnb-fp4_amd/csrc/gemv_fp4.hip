@@ -23,8 +23,8 @@
 //    exact x @ dequant(W)^T than the reference's, not bit-identical to it.
 //  * cross-lane sum: DPP row rotations (16 lanes) + ds_swizzle (32) + v_readlane (64); no LDS
 //    scratch, no barrier.
-// f32 activations: the same register-x geometry; the fp16 pairs of 12*code are widened by v_fma_mix_f32 against the f32 x
-// (the bit-faithful CODE_PARAM f32 table through LDS stays selectable, and serves K > 8192).
+// f32 activations: the same register-x geometry with the bit-faithful CODE_PARAM f32 table in LDS (a table-free variant that
+// widens fp16 pairs of 12*code with v_fma_mix_f32 is selectable: 10 % faster, but k/12 differs from CODE_PARAM by 1e-6).
 // A generic wave-per-row kernel covers every other shape (K % 32 != 0, odd block sizes, huge K).
 #include "fp4_common.h"
 
@@ -942,7 +942,9 @@ int gemv_entry(const void *x, const uint8_t *packed, const float *absmax, const 
                      ? dispatch16<FP4_DTYPE_F16>(variant, x, packed, absmax, bias, out, (int)M, (int)K, bs_shift, out_f32, s)
                      : dispatch16<FP4_DTYPE_BF16>(variant, x, packed, absmax, bias, out, (int)M, (int)K, bs_shift, out_f32, s);
     } else if (fast && g_gemv_variant != 0 &&
-               dispatch32_regx(g_gemv_variant < 0 || ((g_gemv_variant >> 8) & 1), g_gemv_variant < 0 ? 0 : (g_gemv_variant & 0xFF), x,
+               // default: the bit-faithful CODE_PARAM f32 table (the all-f32 reference kernel is accurate to ~1e-7, so the
+               // table's 1e-6 deviations from k/12 are visible at f32); variant bit 8 selects the table-free decode (+10 %)
+               dispatch32_regx(g_gemv_variant >= 0 && ((g_gemv_variant >> 8) & 1), g_gemv_variant < 0 ? 0 : (g_gemv_variant & 0xFF), x,
                                packed, absmax, bias, out, (int)M, (int)K, bs_shift, s) == FP4_OK) {
         rc = FP4_OK;  // f32 activations, register-x geometry (variant 0 forces the LDS kernel below, for sweeps)
     } else if (fast) {
