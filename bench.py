@@ -345,6 +345,13 @@ def main():
             traffic, src = committed_traffic(prefix)
             line[key]["traffic"] = traffic
             line[key]["traffic_source"] = src
+        def spread(ms, launches):  # median and inter-quartile range over the timed steps, us per launch (rank 0)
+            us = sorted(v * 1e3 / launches for v in ms)
+            q = statistics.quantiles(us, n=4) if len(us) >= 4 else [us[0], us[len(us) // 2], us[-1]]
+            return {"median_us": round(q[1], 3), "iqr_us": round(q[2] - q[0], 3), "min_us": round(us[0], 3), "max_us": round(us[-1], 3)}
+
+        line["dequant_step_spread"] = spread(dq_ms, R)
+        line["gemv_step_spread"] = spread(gv_ms, R * GR)
         line.update(extra)
         if "dequant_plus_hipblaslt_gemv_us" in extra:
             line["fused_gemv_speedup_vs_dequant_hipblaslt"] = round(extra["dequant_plus_hipblaslt_gemv_us"] / gv_us, 2)

@@ -47,7 +47,7 @@ __global__ __launch_bounds__(THREADS) void dq(const uint8_t *__restrict__ packed
     constexpr int kVals = 8;
     constexpr int kTile = THREADS * LOADS * kVals;
     constexpr int kMaxAbs = kTile / 32;
-    __shared__ float s_lut[16];
+    __shared__ float s_lut[ABSMODE == 2 ? 16 * (THREADS / 64) : 16];
     __shared__ float s_abs[kMaxAbs];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t e_base = int64_t(blockIdx.x) * kTile;
@@ -81,18 +81,31 @@ __global__ __launch_bounds__(THREADS) void dq(const uint8_t *__restrict__ packed
             if (i < n_abs) s_abs[i] = am_reg[r];
         }
     }
-    if (tid < 16) s_lut[tid] = lut_entry(tid);
-    __syncthreads();
+    if constexpr (ABSMODE == 2) {  // each wave stages the scales of its own span; wave-level sync only (bs = 64)
+        constexpr int per_wave = 64 * LOADS * kVals / 64;  // scales per wave
+        static_assert(per_wave <= 64, "one scale per lane at most");
+        float a = 0.f;
+        if (lane < per_wave) a = abs_src[wave * per_wave + lane];
+        if (lane < 16) s_lut[wave * 16 + lane] = lut_entry(lane);
+        if (lane < per_wave) s_abs[wave * per_wave + lane] = a;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
+        if (tid < 16) s_lut[tid] = lut_entry(tid);
+        __syncthreads();
+    }
     __amdgpu_buffer_rsrc_t rsrc;
     if constexpr (USE_BUFFER) rsrc = __builtin_amdgcn_make_buffer_rsrc(out, 0, out_bytes, 0x00020000);
 #pragma unroll
     for (int j = 0; j < LOADS; ++j) {
         const int word = wave * (64 * LOADS) + j * 64 + lane;
         const int e_local = word * kVals;
-        const float am = ABSMODE == 0 ? s_abs[e_local >> bs_shift] : am_direct[j];
+        const float am = ABSMODE == 1 ? am_direct[j] : s_abs[e_local >> bs_shift];
+        const float *lut = ABSMODE == 2 ? s_lut + wave * 16 : s_lut;
         float v[kVals];
 #pragma unroll
-        for (int i = 0; i < kVals; ++i) v[i] = s_lut[nibble_of(q[j], i)] * am;
+        for (int i = 0; i < kVals; ++i) v[i] = lut[nibble_of(q[j], i)] * am;
         u32x4 o = {pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
         if constexpr (USE_BUFFER) {
             __builtin_amdgcn_raw_buffer_store_b128(o, rsrc, (int)((e_base + e_local) * 2), 0, STORE_AUX);
@@ -150,6 +163,11 @@ int main(int argc, char **argv) {
         {"L4 T256 buf nt sc0       ", launch<4, 256, 3, true, false, 0>},
         {"L4 T256 buf nt sc0 sc1   ", launch<4, 256, 19, true, false, 0>},
         {"L4 T256 nt + nt loads    ", launch<4, 256, 2, false, true, 0>},
+        {"L4 T256 nt ntld wave-sync", launch<4, 256, 2, false, true, 2>},
+        {"L8 T256 nt ntld wave-sync", launch<8, 256, 2, false, true, 2>},
+        {"L4 T128 nt ntld wave-sync", launch<4, 128, 2, false, true, 2>},
+        {"L4 T64 nt ntld wave-sync ", launch<4, 64, 2, false, true, 2>},
+        {"L4 T512 nt ntld wave-sync", launch<4, 512, 2, false, true, 2>},
         {"L4 T256 nt absmax direct ", launch<4, 256, 2, false, false, 1>},
         {"L4 T256 nt ntld absdirect", launch<4, 256, 2, false, true, 1>},
         {"L2 T256 nt               ", launch<2, 256, 2, false, false, 0>},
