@@ -62,6 +62,27 @@ def concat_rows(weights: Sequence[Tuple[torch.Tensor, torch.Tensor, Sequence[int
     return packed, absmax, (sum(int(w[2][0]) for w in weights), K)
 
 
+def _on_host_backend(group) -> bool:
+    return dist.get_backend(group) == "gloo"
+
+
+def _all_reduce_sum(t: torch.Tensor, group) -> torch.Tensor:
+    """Sum across ranks; with the gloo backend (CPU rehearsal of the RCCL path) GPU tensors are staged through the host."""
+    if t.is_cuda and _on_host_backend(group):
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        return h.to(t.device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
+def _all_gather_last(y: torch.Tensor, world: int, group) -> torch.Tensor:
+    src = y.contiguous().cpu() if (y.is_cuda and _on_host_backend(group)) else y.contiguous()
+    parts = [torch.empty_like(src) for _ in range(world)]
+    dist.all_gather(parts, src, group=group)
+    return torch.cat(parts, dim=-1).to(y.device)
+
+
 def _quant_data(packed, absmax, shape, blocksize, bias, use_codebook_dequant=True) -> QuantData:
     state = QuantState(absmax, shape, fp4_code().to(packed.device), blocksize)
     return QuantData(packed, state, state.shape, original_lin=None, bias=bias, use_codebook_dequant=use_codebook_dequant)
@@ -85,9 +106,7 @@ class ColumnParallelFP4Linear(nn.Module):
         y = self.quant_data.forward(x)
         if not self.gather_output or self.world == 1:
             return y
-        parts = [torch.empty_like(y) for _ in range(self.world)]
-        dist.all_gather(parts, y.contiguous(), group=self.group)
-        return torch.cat(parts, dim=-1)
+        return _all_gather_last(y, self.world, self.group)
 
 
 class RowParallelFP4Linear(nn.Module):
@@ -118,7 +137,7 @@ class RowParallelFP4Linear(nn.Module):
                 qd.set_compute_type(xs)
             part = torch.nn.functional.linear(xs, qd.dequantize()).float()
         if self.world > 1:
-            dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.group)
+            part = _all_reduce_sum(part, self.group)
         y = part.to(x.dtype)
         if self.bias is not None:
             y = y + self.bias.to(x.dtype)
