@@ -22,8 +22,7 @@ pytestmark = pytest.mark.gpu
 DTYPES = [torch.bfloat16, torch.float16, torch.float32]
 HALF_ULP = {torch.bfloat16: 2.0**-8, torch.float16: 2.0**-11, torch.float32: 0.0}
 VARIANTS16 = [r | (w << 8) | (u << 16) for (r, w, u) in
-              [(1, 4, 1), (1, 4, 2), (2, 4, 1), (2, 4, 2), (4, 4, 1), (4, 4, 2), (1, 8, 1), (1, 8, 2), (2, 8, 1), (2, 8, 2),
-               (4, 8, 1), (4, 8, 2), (1, 16, 2), (2, 16, 2)]] + [(1 << 24) | it for it in (1, 2, 4, 8)]  # + register-x family
+              [(1, 4, 1), (1, 4, 2), (2, 4, 2), (1, 8, 2), (2, 8, 2), (1, 16, 2)]] + [(1 << 24) | it for it in (1, 2, 4, 8)]  # + register-x family
 
 
 @pytest.fixture(autouse=True)

@@ -1,31 +1,32 @@
-// Fused batch-1 FP4 GEMV for gfx950 (MI355X):  out[r] = sum_k x[k] * code[nib(r,k)] * absmax[(r*K+k)/bs].
+// Fused FP4 GEMV (and its small-batch companion) for gfx950 (MI355X):
+//     out[r] = sum_k x[k] * code[nib(r,k)] * absmax[(r*K+k)/bs]      (+ bias[r])
 //
-// Replaces gemv_4bit_inference_kernel / gemv_4bit_inference_kernel_float and their host
-// dispatcher (reference csrc/gemv_fp4_optimized.cu:60-368).  HBM-bound (0.5625 B of weight
-// stream per 2 flops), so no MFMA; what limits a naive wave64 kernel on this chip is VALU and
-// LDS issue, not memory: at 8 TB/s each CU must retire ~23 weights per clock, i.e. a budget of
-// ~5 VALU lane-ops per weight, and one LDS LUT read per weight would saturate the LDS pipe.
+// Replaces gemv_4bit_inference_kernel / gemv_4bit_inference_kernel_float and their host dispatcher
+// (reference csrc/gemv_fp4_optimized.cu:60-368).  2 flops per 0.5625 B of weight stream: no MFMA.  What limits a
+// wave64 GEMV on this chip is VALU / LDS issue and launch + HBM latency, not bandwidth: at 8 TB/s each CU must retire
+// ~23 weights per clock, v_perm_b32 / v_dot2c / v_fma_mix issue at half rate (profiles/r01_b_exp_valu_issue_rates.txt),
+// and one LDS table read per weight would saturate the LDS pipe.
 //
-// Mapping (16-bit activations, the decode path):
-//  * one wave64 per output row (ROWS rows per wave, WAVES waves per workgroup); lane l owns
-//    16-byte chunks l, l+64, ... of the row = 32 weights each, always inside one quant block;
-//    all chunk loads of a trip are issued before any arithmetic.
-//  * the activation vector is staged once per workgroup in LDS, pre-permuted so that a lane's
-//    four ds_read_b128 are bank-conflict-free and line up with the decode below.
-//  * nibble -> value WITHOUT an LDS table: 12*|code| = {0, 1/16, 8, 12, 4, 6, 2, 3} is exact in
-//    fp16 and bf16, and its fp16 pattern fits one byte, so a v_perm_b32 with the 8-entry byte
-//    table as its 64-bit pool decodes four nibbles per instruction (bf16 needs a second byte
-//    plane).  Signs are OR-ed in from nibble bit 3.  Pairs feed v_dot2_f32_f16 / v_dot2_f32_bf16
-//    (f32 accumulate), ~2 VALU ops per weight in total.
-//  * absmax is factored out of the chunk: acc += absmax * sum_32(x * 12code); the final 1/12
-//    is applied once per row.  Accumulation is f32 throughout (the reference accumulates in
-//    half/bf16 per lane, csrc/gemv_fp4_optimized.cu:87,146-148), so results are closer to the
-//    exact x @ dequant(W)^T than the reference's, not bit-identical to it.
-//  * cross-lane sum: DPP row rotations (16 lanes) + ds_swizzle (32) + v_readlane (64); no LDS
-//    scratch, no barrier.
-// f32 activations: the same register-x geometry with the bit-faithful CODE_PARAM f32 table in LDS (a table-free variant that
-// widens fp16 pairs of 12*code with v_fma_mix_f32 is selectable: 10 % faster, but k/12 differs from CODE_PARAM by 1e-6).
-// A generic wave-per-row kernel covers every other shape (K % 32 != 0, odd block sizes, huge K).
+// Shared building blocks
+//  * decode8: nibble -> value WITHOUT a table in memory.  12*|code| = {0, 1/16, 8, 12, 4, 6, 2, 3} is exact in fp16 and
+//    bf16 and its fp16 pattern fits one byte, so one v_perm_b32 whose 64-bit pool is the 8-entry byte table decodes four
+//    nibbles (bf16: a second byte plane); signs are OR-ed in from nibble bit 3; v_perm_b32 again pairs the bytes up for
+//    v_dot2_f32_f16 / v_dot2_f32_bf16 (f32 accumulate).  ~2.5 issue slots per weight.
+//  * absmax is factored out of every 32-weight chunk (acc += absmax * sum x*12code); 1/12 is applied once per row.
+//    Accumulation is f32 throughout (the reference accumulates per lane in half/bf16, csrc/gemv_fp4_optimized.cu:87,
+//    146-148), so results are closer to the exact x @ dequant(W)^T than the reference's, not bit-identical to it.
+//  * two ordering rules: x (L2-resident) is requested BEFORE the HBM weight stream, because vector-memory results return
+//    in issue order; and load phases are branch-free (clamped index + zero scale), because a load under a divergent `if`
+//    makes hipcc drain the queue with vmcnt(0) at the join.
+//
+// Kernels, in file order
+//  * gemv16_kernel        - LDS geometry (the north-star mapping): one wave64 per row, x staged once per workgroup in a
+//                           pre-permuted, bank-conflict-free LDS image; serves K > 16384 and stays selectable for sweeps.
+//  * gemv16_regx_kernel   - register-x geometry, the DEFAULT for 16-bit activations: a lane owns the same K-chunks for every
+//                           row of its workgroup, so its slice of x lives in VGPRs; K split across the 4 waves.
+//  * gemm16_small_kernel  - the same with 2..8 activation rows (fp4_hip_gemm_small).
+//  * gemv32_kernel / gemv32_regx_kernel - f32 activations (bit-faithful CODE_PARAM f32 table in LDS).
+//  * gemv_generic_kernel  - any even K / blocksize, unaligned operands.
 #include "fp4_common.h"
 
 namespace fp4 {
@@ -648,9 +649,7 @@ int dispatch16(int variant, const void *x, const uint8_t *W, const float *absmax
 #define FP4_V(R, Wv, U)                  \
     case (R | (Wv << 8) | (U << 16)):    \
         return launch16<DT, R, Wv, U>(x, W, absmax, bias, out, M, K, bs_shift, out_f32, stream);
-        FP4_V(1, 4, 1) FP4_V(1, 4, 2) FP4_V(2, 4, 1) FP4_V(2, 4, 2) FP4_V(4, 4, 1) FP4_V(4, 4, 2)
-        FP4_V(1, 8, 1) FP4_V(1, 8, 2) FP4_V(2, 8, 1) FP4_V(2, 8, 2) FP4_V(4, 8, 1) FP4_V(4, 8, 2)
-        FP4_V(1, 16, 2) FP4_V(2, 16, 2)
+        FP4_V(1, 4, 1) FP4_V(1, 4, 2) FP4_V(2, 4, 2) FP4_V(1, 8, 2) FP4_V(2, 8, 2) FP4_V(1, 16, 2)
 #undef FP4_V
         default:
             set_error("fp4_hip_gemv: unknown kernel variant 0x%x", variant);
