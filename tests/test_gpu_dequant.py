@@ -158,3 +158,24 @@ def test_cache_policy_flags_do_not_change_bits(dtype):
     P, A = to_dev(packed), to_dev(am)
     for flags in (hipabi.AUTO, hipabi.KEEP_CACHED, hipabi.STREAM):
         assert np.array_equal(bits(hipabi.dequantize(P, A, 64, n, dtype, flags=flags)), want), flags
+
+
+def test_beyond_32bit_element_indices():
+    """n > 2^31 elements (a 1 GiB packed weight -> 4 GiB of bf16): every index computation must be 64-bit.  The oracle
+    is evaluated on slices around the 2^31 / 2^32-byte boundaries and at the very end, not on the whole tensor."""
+    bs = 64
+    n = (1 << 31) + 8192 * 3 + 64  # > INT32_MAX elements, whole tiles plus a generic tail
+    gen = torch.Generator(device=dev()).manual_seed(9)
+    packed = torch.randint(0, 256, (n // 2,), dtype=torch.uint8, device=dev(), generator=gen)
+    absmax = torch.rand(n // bs, device=dev(), generator=gen) + 0.25
+    out = hipabi.dequantize(packed, absmax, bs, n, torch.bfloat16)
+    torch.cuda.synchronize()
+    for start in (0, (1 << 30) - 4096, (1 << 31) - 8192, (1 << 31) - 64, (1 << 31), n - 8192 * 3 - 64 - 4096, n - 4096):
+        start -= start % bs
+        cnt = min(8192, n - start)
+        p = packed[start // 2:(start + cnt) // 2].cpu().numpy()
+        a = absmax[start // bs:(start + cnt + bs - 1) // bs].cpu().numpy()
+        want = np_bits(o.dequantize(p, a, bs, cnt, "bfloat16"))
+        assert np.array_equal(bits(out[start:start + cnt]), want), start
+    del out, packed, absmax
+    torch.cuda.empty_cache()

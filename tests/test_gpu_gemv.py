@@ -237,3 +237,25 @@ def test_degenerate_sizes():
     assert hipabi.gemv(x, P, A, 0, 64, 64).numel() == 0  # M = 0
     y = hipabi.gemv(x[:0], P, A, 2, 0, 64)  # K = 0: empty sum
     assert torch.equal(y.float(), torch.zeros(2, device=dev()))
+
+
+def test_gemv_beyond_32bit_weight_indices():
+    """M*K > 2^31 weights: the last rows of a 2^19 x 4608 weight must still be addressed correctly (64-bit chunk index)."""
+    M, K, bs = 1 << 19, 4608, 64  # 2.4e9 weights, 1.2 GB packed
+    gen = torch.Generator(device=dev()).manual_seed(4)
+    packed = torch.randint(0, 256, (M * K // 2,), dtype=torch.uint8, device=dev(), generator=gen)
+    absmax = torch.rand(M * K // bs, device=dev(), generator=gen) * 0.05 + 0.01
+    x = torch.randn(K, device=dev(), generator=gen).to(torch.bfloat16)
+    y = hipabi.gemv(x, packed, absmax, M, K, bs)
+    torch.cuda.synchronize()
+    xv = x.float().cpu().numpy().astype(np.float64)
+    for r0 in (0, (1 << 31) // K - 2, M - 4):
+        rows = 4
+        p = packed[r0 * K // 2:(r0 + rows) * K // 2].cpu().numpy()
+        a = absmax[r0 * K // bs:(r0 + rows) * K // bs].cpu().numpy()
+        exact = c_oracle.gemv_f64(xv, p, a, rows, K, bs)
+        scale = np.abs(o.dequantize_f32(p, a, bs, rows * K).reshape(rows, K).astype(np.float64)) @ np.abs(xv)
+        got = y[r0:r0 + rows].float().cpu().numpy()
+        assert (np.abs(got - exact) <= 2.0**-8 * 1.01 * np.abs(exact) + 1e-5 * scale).all(), r0
+    del packed, absmax, y
+    torch.cuda.empty_cache()
