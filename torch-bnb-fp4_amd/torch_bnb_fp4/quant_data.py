@@ -107,28 +107,31 @@ class QuantData:
 
     # -- dispatcher ------------------------------------------------------------------------------
     def forward(self, A: torch.Tensor) -> torch.Tensor:
-        total = prod(A.shape)
+        total = A.numel()
+        K = A.shape[-1]
+        # hot path first (224 calls per token in a 7B model; eager decode is host-bound): single token, 2-D or 3-D
+        if total == K and total != 0 and self.compute_dtype_set and K % self.blocksize == 0:
+            nd = A.ndim
+            if nd == 2 or nd == 3:
+                if not A.is_contiguous():
+                    A = A.contiguous()
+                bias = self.bias
+                if nd == 2:
+                    out = self._qgemv(A, bias if self.fuse_bias else None)
+                else:
+                    out = self._qgemv(A.view(-1, K), bias if self.fuse_bias else None).view(A.shape[0], 1, -1)
+                if bias is not None and not self.fuse_bias:
+                    out += bias
+                return out
         if total == 0:
             w_shape = self.quant_state.shape
-            tail = w_shape[1:] if A.shape[-1] == w_shape[0] else w_shape[:1]
+            tail = w_shape[1:] if K == w_shape[0] else w_shape[:1]
             return torch.empty(A.shape[:-1] + tail, dtype=A.dtype, device=A.device)
         if not self.compute_dtype_set:
             self.set_compute_type(A)
-        K = A.shape[-1]
-        single_token = total == K
-        if not single_token or K % self.blocksize != 0 or A.ndim not in (2, 3):
-            if (self.small_batch_fused and 2 <= total // K <= 8 and K % self.blocksize == 0 and K % 32 == 0 and K <= 4096
-                    and A.dtype in (torch.float16, torch.bfloat16)):
-                return ext.gemm_small_fp4(A.contiguous(), self.A.t(), self.absmax, self.blocksize,
-                                          list(self.quant_state.shape), self.bias)
-            return self.qlinear(A)
-        if not A.is_contiguous():
-            A = A.contiguous()
-        lead = A.shape[0]
-        fused = self.bias if self.fuse_bias else None
-        out = self._qgemv(A.view(-1, K), fused)
-        if A.ndim == 3:
-            out = out.view(lead, 1, -1)
-        if self.bias is not None and fused is None:
-            out += self.bias
-        return out
+            return self.forward(A)
+        # everything that is not a 2-D / 3-D single token with K % blocksize == 0 (:593-594, :614-617)
+        if (self.small_batch_fused and 2 <= total // K <= 8 and K % self.blocksize == 0 and K % 32 == 0 and K <= 4096
+                and A.dtype in (torch.float16, torch.bfloat16)):
+            return ext.gemm_small_fp4(A.contiguous(), self.A.t(), self.absmax, self.blocksize, self._shape_list, self.bias)
+        return self.qlinear(A)
