@@ -195,21 +195,28 @@ def test_partial_f32_output_and_k_split_sum(dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("B", [1, 2, 3, 4, 5, 8])
-@pytest.mark.parametrize("M,K", [(4096, 4096), (1024, 4096), (2048, 768), (66, 2048), (257, 1024), (300, 8192), (40, 14336)])
-def test_small_batch_fused_gemm(dtype, B, M, K):
-    """fp4_hip_gemm_small: 1..8 activation rows against the float64 product, same bar as the GEMV (one rounding)."""
+@pytest.mark.parametrize("kernel", [0, 1])  # 0 = VALU kernel, 1 = matrix-core kernel
+@pytest.mark.parametrize("B", [1, 2, 3, 4, 5, 8, 9, 13, 16])
+@pytest.mark.parametrize("M,K", [(4096, 4096), (1024, 4096), (2048, 768), (66, 2048), (257, 1024), (300, 8192), (40, 14336), (33, 512)])
+def test_small_batch_fused_gemm(dtype, kernel, B, M, K):
+    """fp4_hip_gemm_small: 1..16 activation rows against the float64 product, same bar as the GEMV (one rounding);
+    both kernels, every shape class (VALU band splits, MFMA blocks-per-wave 1/2/4/8, ragged M, B not a power of two)."""
     packed, am, _ = make_case(M, K, seed=B * 1000 + M)
     rng = np.random.default_rng(B)
     x = rng.standard_normal((B, K)).astype(np.float32)
     bias = rng.standard_normal(M).astype(np.float32) * 0.1
     x_t, b_t = torch_values(x, dtype), torch_values(bias, dtype)
-    covered = (K // 32 <= 128) or (K // 32 <= 256 and B <= 4) or (K // 32 <= 512 and B <= 2)
-    if not covered:
-        rc = hipabi.gemm_small(x_t, to_dev(packed), to_dev(am), M, K, 64, expect_ok=False)
-        assert rc == hipabi.ERR_UNSUPPORTED and "dequant + GEMM" in hipabi.last_error()
-        return
-    y = hipabi.gemm_small(x_t, to_dev(packed), to_dev(am), M, K, 64, bias=b_t)
+    valu_ok = B <= 8 and ((K // 32 <= 128) or (K // 32 <= 256 and B <= 4) or (K // 32 <= 512 and B <= 2))
+    mfma_ok = K % 512 == 0
+    hipabi.set_variant("gemm_small", kernel)
+    try:
+        if not (valu_ok or mfma_ok):
+            rc = hipabi.gemm_small(x_t, to_dev(packed), to_dev(am), M, K, 64, expect_ok=False)
+            assert rc == hipabi.ERR_UNSUPPORTED and "dequant + GEMM" in hipabi.last_error()
+            return
+        y = hipabi.gemm_small(x_t, to_dev(packed), to_dev(am), M, K, 64, bias=b_t)
+    finally:
+        hipabi.set_variant("gemm_small", -1)
     wabs = np.abs(o.dequantize_f32(packed, am, 64, M * K).reshape(M, K).astype(np.float64))
     bv = b_t.float().cpu().numpy().astype(np.float64)
     for b in range(B):

@@ -39,8 +39,15 @@ def timeit(replay, launches, reps=7):
     return statistics.median(ts)
 
 
-for B in (1, 2, 4, 8):
+for B in (1, 2, 3, 4, 8, 12, 16):
     x = torch.randn(B, K, device=dev).to(torch.bfloat16)
+    per_kernel = {}
+    for kname, kv in (("valu", 0), ("mfma", 1)):
+        if kv == 0 and B > 8:
+            continue
+        hipabi.set_variant("gemm_small", kv)
+        per_kernel[kname] = timeit(capture(lambda: [hipabi.gemm_small(x, packed[i], absmax[i], M, K, 64) for i in range(R)]), R)
+    hipabi.set_variant("gemm_small", -1)
     fused = capture(lambda: [hipabi.gemm_small(x, packed[i], absmax[i], M, K, 64) for i in range(R)])
 
     def ref():
@@ -49,4 +56,5 @@ for B in (1, 2, 4, 8):
             torch.nn.functional.linear(x, wbuf[i])
 
     t_f, t_r = timeit(fused, R), timeit(capture(ref), R)
-    print(f"{M}x{K} bf16 batch {B}: fused {t_f:6.2f} us   dequant+hipBLASLt {t_r:6.2f} us   speedup {t_r / t_f:4.1f}x", flush=True)
+    print(f"{M}x{K} bf16 batch {B:2d}: fused {t_f:6.2f} us ({', '.join(f'{k} {v:.2f}' for k, v in per_kernel.items())})   "
+          f"dequant+hipBLASLt {t_r:6.2f} us   speedup {t_r / t_f:4.1f}x", flush=True)

@@ -13,6 +13,7 @@ thread_local char g_last_error[512] = "";
 
 void set_dequant_variant(int v);
 void set_gemv_variant(int v);
+void set_small_variant(int v);
 
 void set_error(const char *fmt, ...) {
     va_list ap;
@@ -53,6 +54,10 @@ extern "C" int fp4_hip_set_variant(const char *kernel, int variant) {
     }
     if (kernel && !std::strcmp(kernel, "gemv")) {
         fp4::set_gemv_variant(variant);
+        return FP4_OK;
+    }
+    if (kernel && !std::strcmp(kernel, "gemm_small")) {
+        fp4::set_small_variant(variant);
         return FP4_OK;
     }
     fp4::set_error("fp4_hip_set_variant: unknown kernel '%s'", kernel ? kernel : "(null)");

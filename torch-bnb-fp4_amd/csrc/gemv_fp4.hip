@@ -613,6 +613,7 @@ __global__ __launch_bounds__(256) void gemv_generic_kernel(const void *__restric
     }
 }
 
+int g_small_variant = -1;  // fp4_hip_gemm_small: -1 heuristic, 0 VALU kernel, 1 matrix-core kernel (sweeps)
 int g_gemv_variant = -1;  // LDS geometry: ROWS | WAVES << 8 | UNROLL << 16; register-x geometry: 1 << 24 | KSPLIT_override << 8 | ITERS; -1 = heuristic
 
 constexpr int kMaxLdsBytes = 160 * 1024 - 256;
@@ -781,6 +782,136 @@ __global__ __launch_bounds__(256) void gemm16_small_kernel(const uint16_t *__res
     }
 }
 
+// ---- small batch on the matrix cores (2..16 activation rows) -----------------------------------------------------
+// With up to 16 activation rows the product is GEMM-shaped enough for v_mfma_f32_16x16x32: M-dim = 16 weight rows,
+// N-dim = the (up to 16) activation rows, K-dim = 32 weights.  The dot work moves from the VALU to the matrix pipe, so
+// the cost no longer grows with the batch (the VALU small-batch kernel above pays 4 v_dot2 per row per 8 weights);
+// the VALU only decodes (decode8: the four dwords it returns ARE the A fragment, with the k order of the 8-group
+// permuted the same way on the B side).
+//   * workgroup = 8 waves = one 16-row tile of W; the 8 waves split K (wave w owns quant blocks w*NBW.. of every pass);
+//   * lane (r = l&15, kb = l>>4) supplies, per 64-weight quant block, the 8 packed bytes [8kb, 8kb+8) of row r: two
+//     MFMAs per block (k-sets {16kb + 8t + j}), so one MFMA never straddles two scales; the block's partial tile is
+//     scaled by absmax[row(reg), block] and added to the f32 accumulator (4 FMAs per 2 MFMAs);
+//   * the B operand is x[n = l&15][64b + 16kb + 8t + j], loaded straight from L2 into VGPRs (32 B per block);
+//   * the 8 partial 16x16 tiles meet in LDS; one rounding, bias added in f32 first (F.linear semantics).
+// Needs blocksize 64 and K a multiple of 512; everything else is served by the kernels above or by dequant + GEMM.
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+
+template <int DT>
+__device__ __forceinline__ f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c) {
+    if constexpr (DT == FP4_DTYPE_F16)
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+
+template <int DT, int NBW>
+__global__ __launch_bounds__(512) void gemm16_mfma_kernel(const uint16_t *__restrict__ x, const uint8_t *__restrict__ W,
+                                                          const float *__restrict__ absmax,
+                                                          const uint16_t *__restrict__ bias, uint16_t *__restrict__ out,
+                                                          int B, int M, int K) {
+    __shared__ __attribute__((aligned(16))) float s_part[8][256];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int r = lane & 15, kb = lane >> 4;
+    const int row0 = blockIdx.x * 16;
+    const int nblk = K >> 6;
+    const int passes = nblk / (8 * NBW);
+    const int64_t row_a = row0 + r < M ? row0 + r : M - 1;  // clamped rows / batch entries are computed, never stored
+    const int64_t n_b = r < B ? r : B - 1;
+    int64_t row_d[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) row_d[g] = row0 + kb * 4 + g < M ? row0 + kb * 4 + g : M - 1;
+    const u32x4 *x4 = reinterpret_cast<const u32x4 *>(x);
+    const u32x2 *W2 = reinterpret_cast<const u32x2 *>(W);
+
+    f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int p = 0; p < passes; ++p) {
+        const int b0 = (p * 8 + wave) * NBW;
+        // x first (L2), then the weight stream (HBM), then the scales; all branch-free
+        u32x4 xr[NBW][2];
+#pragma unroll
+        for (int j = 0; j < NBW; ++j) {
+            const int64_t e = n_b * K + 64 * (b0 + j) + 16 * kb;
+            xr[j][0] = x4[e >> 3];
+            xr[j][1] = x4[(e >> 3) + 1];
+        }
+        u32x2 wq[NBW];
+#pragma unroll
+        for (int j = 0; j < NBW; ++j) wq[j] = __builtin_nontemporal_load(W2 + ((row_a * K) >> 4) + 4 * (b0 + j) + kb);
+        float am[4][NBW];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float *src = absmax + row_d[g] * nblk + b0;
+            if constexpr (NBW % 4 == 0) {
+#pragma unroll
+                for (int j = 0; j < NBW; j += 4) {
+                    const f32x4 v = *reinterpret_cast<const f32x4 *>(src + j);
+                    am[g][j] = v.x, am[g][j + 1] = v.y, am[g][j + 2] = v.z, am[g][j + 3] = v.w;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < NBW; ++j) am[g][j] = src[j];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NBW; ++j) {
+            f32x4 tile = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const u32x4 w = xr[j][t];
+                u32x4 bfrag;
+                bfrag.x = perm(w.y, w.x, 0x05040100u);  // (x0,x2)
+                bfrag.y = perm(w.w, w.z, 0x05040100u);  // (x4,x6)
+                bfrag.z = perm(w.y, w.x, 0x07060302u);  // (x1,x3)
+                bfrag.w = perm(w.w, w.z, 0x07060302u);  // (x5,x7)
+                uint32_t P[4];
+                decode8<DT>(t == 0 ? wq[j].x : wq[j].y, P);
+                const u32x4 afrag = {P[0], P[1], P[2], P[3]};
+                tile = mfma16<DT>(afrag, bfrag, tile);
+            }
+            acc.x = __builtin_fmaf(tile.x, am[0][j], acc.x);
+            acc.y = __builtin_fmaf(tile.y, am[1][j], acc.y);
+            acc.z = __builtin_fmaf(tile.z, am[2][j], acc.z);
+            acc.w = __builtin_fmaf(tile.w, am[3][j], acc.w);
+        }
+    }
+    *reinterpret_cast<f32x4 *>(&s_part[wave][lane * 4]) = acc;
+    __syncthreads();
+    if (tid < 256) {
+        float t = 0.0f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) t += s_part[w][tid];
+        const int l = tid >> 2, reg = tid & 3;  // D layout: col = l & 15 (activation row), row = (l >> 4) * 4 + reg (weight row)
+        const int n = l & 15, row = row0 + (l >> 4) * 4 + reg;
+        if (row < M && n < B) {
+            t *= (1.0f / 12.0f);
+            if (bias) t += to_f32<DT>(bias[row]);
+            out[int64_t(n) * M + row] = from_f32<DT>(t);
+        }
+    }
+}
+
+template <int DT>
+int dispatch_mfma(const void *x, const uint8_t *W, const float *absmax, const void *bias, void *out, int B, int M, int K,
+                  hipStream_t stream) {
+    if (K % 512) return -1;
+    const unsigned blocks = (unsigned)((M + 15) / 16);
+    const int units = K / 512;  // quant blocks per wave over the whole K
+#define FP4_MF(NBW)                                                                                                   \
+    hipLaunchKernelGGL((gemm16_mfma_kernel<DT, NBW>), dim3(blocks), dim3(512), 0, stream,                             \
+                       reinterpret_cast<const uint16_t *>(x), W, absmax, reinterpret_cast<const uint16_t *>(bias),    \
+                       reinterpret_cast<uint16_t *>(out), B, M, K);                                                   \
+    return FP4_OK
+    if (units % 8 == 0) { FP4_MF(8); }
+    if (units % 4 == 0) { FP4_MF(4); }
+    if (units % 2 == 0) { FP4_MF(2); }
+    FP4_MF(1);
+#undef FP4_MF
+}
+
 template <int DT, int KSPLIT, int G, int ITERS, int NB>
 int launch_small(const void *x, const uint8_t *W, const float *absmax, const void *bias, void *out, int B, int M, int K,
                  int bs_shift, hipStream_t stream) {
@@ -892,6 +1023,7 @@ int run_generic(const void *x, const uint8_t *W, const float *absmax, const void
 }  // namespace
 
 void set_gemv_variant(int v) { g_gemv_variant = v; }
+void set_small_variant(int v) { g_small_variant = v; }
 
 }  // namespace fp4
 
@@ -986,8 +1118,8 @@ extern "C" int fp4_hip_gemv_partial(const void *x, const uint8_t *packed, const 
 extern "C" int fp4_hip_gemm_small(const void *x, const uint8_t *packed, const float *absmax, const void *bias, void *out,
                                   int64_t B, int64_t M, int64_t K, int blocksize, int dtype, void *stream) {
     using namespace fp4;
-    if (B < 1 || B > 8 || M < 0 || K <= 0) {
-        set_error("fp4_hip_gemm_small: B=%lld M=%lld K=%lld (need 1 <= B <= 8)", (long long)B, (long long)M, (long long)K);
+    if (B < 1 || B > 16 || M < 0 || K <= 0) {
+        set_error("fp4_hip_gemm_small: B=%lld M=%lld K=%lld (need 1 <= B <= 16)", (long long)B, (long long)M, (long long)K);
         return FP4_ERR_INVALID_ARGUMENT;
     }
     if (M == 0) return FP4_OK;
@@ -998,13 +1130,21 @@ extern "C" int fp4_hip_gemm_small(const void *x, const uint8_t *packed, const fl
     const int bs_shift = ilog2_exact(blocksize);
     const uintptr_t align = reinterpret_cast<uintptr_t>(packed) | reinterpret_cast<uintptr_t>(x);
     const bool ok = (dtype == FP4_DTYPE_F16 || dtype == FP4_DTYPE_BF16) && (K % 32) == 0 && bs_shift >= 5 &&
-                    (K % blocksize) == 0 && (align & 15u) == 0 && M <= (int64_t(1) << 30) && K <= 16384;
+                    (K % blocksize) == 0 && (align & 15u) == 0 && M <= (int64_t(1) << 30) && K <= (int64_t(1) << 24);
+    hipStream_t s = static_cast<hipStream_t>(stream);
     int rc = -1;
-    if (ok)
-        rc = dtype == FP4_DTYPE_F16 ? dispatch_small<FP4_DTYPE_F16>(x, packed, absmax, bias, out, (int)B, (int)M, (int)K, bs_shift,
-                                                                    static_cast<hipStream_t>(stream))
-                                    : dispatch_small<FP4_DTYPE_BF16>(x, packed, absmax, bias, out, (int)B, (int)M, (int)K,
-                                                                     bs_shift, static_cast<hipStream_t>(stream));
+    // matrix-core kernel: blocksize 64, K % 512 == 0; ties the VALU kernel at 3-4 rows, wins from 5 up (7.5 vs 11.4 us at 8), mandatory above 8
+    const bool mfma_ok = ok && blocksize == 64 && (K % 512) == 0;
+    const bool want_mfma = g_small_variant == 1 || (g_small_variant < 0 && B >= 5);
+    if (mfma_ok && (want_mfma || B > 8))
+        rc = dtype == FP4_DTYPE_F16 ? dispatch_mfma<FP4_DTYPE_F16>(x, packed, absmax, bias, out, (int)B, (int)M, (int)K, s)
+                                    : dispatch_mfma<FP4_DTYPE_BF16>(x, packed, absmax, bias, out, (int)B, (int)M, (int)K, s);
+    if (rc == -1 && ok && B <= 8 && K <= 16384)
+        rc = dtype == FP4_DTYPE_F16 ? dispatch_small<FP4_DTYPE_F16>(x, packed, absmax, bias, out, (int)B, (int)M, (int)K, bs_shift, s)
+                                    : dispatch_small<FP4_DTYPE_BF16>(x, packed, absmax, bias, out, (int)B, (int)M, (int)K, bs_shift, s);
+    if (rc == -1 && mfma_ok)
+        rc = dtype == FP4_DTYPE_F16 ? dispatch_mfma<FP4_DTYPE_F16>(x, packed, absmax, bias, out, (int)B, (int)M, (int)K, s)
+                                    : dispatch_mfma<FP4_DTYPE_BF16>(x, packed, absmax, bias, out, (int)B, (int)M, (int)K, s);
     if (rc == -1) {
         set_error("fp4_hip_gemm_small: shape B=%lld M=%lld K=%lld blocksize=%d dtype=%d is not covered; use dequant + GEMM",
                   (long long)B, (long long)M, (long long)K, blocksize, dtype);

@@ -181,7 +181,7 @@ torch::Tensor gemv_fp4_bias(torch::Tensor A, torch::Tensor B, torch::Tensor absm
     return gemv_impl(A, B, absmax, datatype, blocksize, dtype, Bshape, bias);
 }
 
-// fused small-batch product: A [..., K] with 1..8 rows in total -> [..., m]; raises if the shape is not covered
+// fused small-batch product: A [..., K] with 1..16 rows in total -> [..., m]; raises if the shape is not covered
 torch::Tensor gemm_small_fp4(torch::Tensor A, torch::Tensor B, torch::Tensor absmax, int blocksize, std::vector<uint32_t> Bshape,
                              c10::optional<torch::Tensor> bias) {
     check_gpu_contiguous(A, "A");
@@ -191,7 +191,7 @@ torch::Tensor gemm_small_fp4(torch::Tensor A, torch::Tensor B, torch::Tensor abs
     const int64_t m = Bshape[0], k = Bshape[1];
     TORCH_CHECK(A.dim() >= 1 && A.size(-1) == k, "gemm_small_fp4: last dim of the activation must be in_features = ", k);
     const int64_t rows = A.numel() / k;
-    TORCH_CHECK(rows >= 1 && rows <= 8, "gemm_small_fp4 covers 1..8 activation rows, got ", rows);
+    TORCH_CHECK(rows >= 1 && rows <= 16, "gemm_small_fp4 covers 1..16 activation rows, got ", rows);
     TORCH_CHECK(B.dtype() == torch::kUInt8 && B.numel() * 2 >= m * k, "B too small for a ", m, "x", k, " weight");
     TORCH_CHECK(absmax.scalar_type() == torch::kFloat32 && absmax.numel() * int64_t(blocksize) >= m * k, "absmax too small");
     const int dt = to_fp4_dtype(A.scalar_type(), "gemm_small_fp4");
@@ -273,7 +273,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("qlinear_codebook_bias", &qlinear_codebook_bias, "codebook dequant + linear + bias");
     // extras
     m.def("gemv_fp4_bias", &gemv_fp4_bias, "gemv_fp4 with the bias add fused into the epilogue");
-    m.def("gemm_small_fp4", &gemm_small_fp4, "fused FP4 product for 1..8 activation rows: (A, B, absmax, blocksize, Bshape, bias|None)");
+    m.def("gemm_small_fp4", &gemm_small_fp4, "fused FP4 product for 1..16 activation rows: (A, B, absmax, blocksize, Bshape, bias|None)");
     m.def("gemv_fp4_partial", &gemv_fp4_partial, "f32 partial sums of a K-split shard: (A, B, absmax, blocksize, Bshape)");
     m.def("quantize_fp4", &quantize_fp4, "blockwise FP4 quantiser: (W, blocksize) -> (packed, absmax)");
     m.def("code_table", &code_table, "16-entry code table as a CPU float tensor");
