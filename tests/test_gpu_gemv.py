@@ -195,7 +195,7 @@ def test_partial_f32_output_and_k_split_sum(dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("kernel", [0, 1])  # 0 = VALU kernel, 1 = matrix-core kernel
+@pytest.mark.parametrize("kernel", [0, 1 | (1 << 4), 1 | (2 << 4), 1 | (1 << 4) | (1 << 8), 1 | (2 << 4) | (1 << 8)])  # VALU kernel; matrix-core kernel: 1 / 2 row tiles, LDS-staged / direct weight loads
 @pytest.mark.parametrize("B", [1, 2, 3, 4, 5, 8, 9, 13, 16])
 @pytest.mark.parametrize("M,K", [(4096, 4096), (1024, 4096), (2048, 768), (66, 2048), (257, 1024), (300, 8192), (40, 14336), (33, 512)])
 def test_small_batch_fused_gemm(dtype, kernel, B, M, K):
@@ -206,6 +206,7 @@ def test_small_batch_fused_gemm(dtype, kernel, B, M, K):
     x = rng.standard_normal((B, K)).astype(np.float32)
     bias = rng.standard_normal(M).astype(np.float32) * 0.1
     x_t, b_t = torch_values(x, dtype), torch_values(bias, dtype)
+    kernel_is_mfma = kernel & 1
     valu_ok = B <= 8 and ((K // 32 <= 128) or (K // 32 <= 256 and B <= 4) or (K // 32 <= 512 and B <= 2))
     mfma_ok = K % 512 == 0
     hipabi.set_variant("gemm_small", kernel)

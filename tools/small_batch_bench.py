@@ -42,7 +42,8 @@ def timeit(replay, launches, reps=7):
 for B in (1, 2, 3, 4, 8, 12, 16):
     x = torch.randn(B, K, device=dev).to(torch.bfloat16)
     per_kernel = {}
-    for kname, kv in (("valu", 0), ("mfma", 1)):
+    for kname, kv in (("valu", 0), ("mfma rt1", 1 | (1 << 4)), ("mfma rt2", 1 | (2 << 4)), ("mfma rt1 direct", 1 | (1 << 4) | (1 << 8)),
+                      ("mfma rt2 direct", 1 | (2 << 4) | (1 << 8))):
         if kv == 0 and B > 8:
             continue
         hipabi.set_variant("gemm_small", kv)

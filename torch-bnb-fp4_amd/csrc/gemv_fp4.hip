@@ -806,28 +806,40 @@ __device__ __forceinline__ f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
 }
 
-template <int DT, int NBW>
+template <int DT, int NBW, int ROWT, bool STAGE>
 __global__ __launch_bounds__(512) void gemm16_mfma_kernel(const uint16_t *__restrict__ x, const uint8_t *__restrict__ W,
                                                           const float *__restrict__ absmax,
                                                           const uint16_t *__restrict__ bias, uint16_t *__restrict__ out,
                                                           int B, int M, int K) {
-    __shared__ __attribute__((aligned(16))) float s_part[8][256];
+    // ROWT 16-row tiles per workgroup share one B fragment (x slice): x is re-read by every workgroup, so taller
+    // workgroups cut that L2 traffic (B*K*2 bytes each) at the price of fewer workgroups
+    __shared__ __attribute__((aligned(16))) float s_part[8][ROWT][256];
+    // STAGE: the A-fragment layout wants 8 bytes per lane from 16 different rows (32-byte segments per row per
+    // instruction); instead each wave pulls its 16 x (32*NBW)-byte region with row-contiguous 16-byte loads and
+    // re-reads it from a padded, bank-conflict-free LDS image (wave-private: no workgroup barrier)
+    constexpr int kStageStride = 32 * NBW + 16;
+    __shared__ __attribute__((aligned(16))) uint8_t s_w[STAGE ? 8 * ROWT * 16 * kStageStride : 16];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int r = lane & 15, kb = lane >> 4;
-    const int row0 = blockIdx.x * 16;
+    const int row0 = blockIdx.x * (16 * ROWT);
     const int nblk = K >> 6;
     const int passes = nblk / (8 * NBW);
-    const int64_t row_a = row0 + r < M ? row0 + r : M - 1;  // clamped rows / batch entries are computed, never stored
-    const int64_t n_b = r < B ? r : B - 1;
-    int64_t row_d[4];
+    const int64_t n_b = r < B ? r : B - 1;  // clamped rows / batch entries are computed, never stored
+    int64_t row_a[ROWT], row_d[ROWT][4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) row_d[g] = row0 + kb * 4 + g < M ? row0 + kb * 4 + g : M - 1;
+    for (int rt = 0; rt < ROWT; ++rt) {
+        row_a[rt] = row0 + 16 * rt + r < M ? row0 + 16 * rt + r : M - 1;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) row_d[rt][g] = row0 + 16 * rt + kb * 4 + g < M ? row0 + 16 * rt + kb * 4 + g : M - 1;
+    }
     const u32x4 *x4 = reinterpret_cast<const u32x4 *>(x);
     const u32x2 *W2 = reinterpret_cast<const u32x2 *>(W);
 
-    f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+    f32x4 acc[ROWT];
+#pragma unroll
+    for (int rt = 0; rt < ROWT; ++rt) acc[rt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     for (int p = 0; p < passes; ++p) {
         const int b0 = (p * 8 + wave) * NBW;
         // x first (L2), then the weight stream (HBM), then the scales; all branch-free
@@ -838,54 +850,103 @@ __global__ __launch_bounds__(512) void gemm16_mfma_kernel(const uint16_t *__rest
             xr[j][0] = x4[e >> 3];
             xr[j][1] = x4[(e >> 3) + 1];
         }
-        u32x2 wq[NBW];
+        u32x2 wq[ROWT][NBW];
+        constexpr int kLanesPerRow = 2 * NBW, kRowsPerInstr = 64 / kLanesPerRow, kInstr = (16 + kRowsPerInstr - 1) / kRowsPerInstr;
+        u32x4 wstage[ROWT][kInstr];
+        if constexpr (STAGE) {
 #pragma unroll
-        for (int j = 0; j < NBW; ++j) wq[j] = __builtin_nontemporal_load(W2 + ((row_a * K) >> 4) + 4 * (b0 + j) + kb);
-        float am[4][NBW];
+            for (int rt = 0; rt < ROWT; ++rt)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const float *src = absmax + row_d[g] * nblk + b0;
-            if constexpr (NBW % 4 == 0) {
-#pragma unroll
-                for (int j = 0; j < NBW; j += 4) {
-                    const f32x4 v = *reinterpret_cast<const f32x4 *>(src + j);
-                    am[g][j] = v.x, am[g][j + 1] = v.y, am[g][j + 2] = v.z, am[g][j + 3] = v.w;
+                for (int i = 0; i < kInstr; ++i) {
+                    const int rr = i * kRowsPerInstr + lane / kLanesPerRow;  // row of the tile this lane fetches
+                    const int64_t row = row0 + 16 * rt + (rr & 15) < M ? row0 + 16 * rt + (rr & 15) : M - 1;
+                    wstage[rt][i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(W) + ((row * K) >> 5) + 2 * b0 +
+                                                               (lane % kLanesPerRow));
                 }
-            } else {
+        } else {
 #pragma unroll
-                for (int j = 0; j < NBW; ++j) am[g][j] = src[j];
+            for (int rt = 0; rt < ROWT; ++rt)
+#pragma unroll
+                for (int j = 0; j < NBW; ++j)
+                    wq[rt][j] = __builtin_nontemporal_load(W2 + ((row_a[rt] * K) >> 4) + 4 * (b0 + j) + kb);
+        }
+        float am[ROWT][4][NBW];
+#pragma unroll
+        for (int rt = 0; rt < ROWT; ++rt) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float *src = absmax + row_d[rt][g] * nblk + b0;
+                if constexpr (NBW % 4 == 0) {
+#pragma unroll
+                    for (int j = 0; j < NBW; j += 4) {
+                        const f32x4 v = *reinterpret_cast<const f32x4 *>(src + j);
+                        am[rt][g][j] = v.x, am[rt][g][j + 1] = v.y, am[rt][g][j + 2] = v.z, am[rt][g][j + 3] = v.w;
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < NBW; ++j) am[rt][g][j] = src[j];
+                }
+            }
+        }
+        if constexpr (STAGE) {
+            if (p > 0) __builtin_amdgcn_wave_barrier();  // the previous pass's reads are done before the image is rewritten
+#pragma unroll
+            for (int rt = 0; rt < ROWT; ++rt) {
+                uint8_t *img = s_w + (wave * ROWT + rt) * 16 * kStageStride;
+#pragma unroll
+                for (int i = 0; i < kInstr; ++i) {
+                    const int rr = i * kRowsPerInstr + lane / kLanesPerRow;
+                    if (rr < 16) *reinterpret_cast<u32x4 *>(img + rr * kStageStride + 16 * (lane % kLanesPerRow)) = wstage[rt][i];
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int rt = 0; rt < ROWT; ++rt) {
+                const uint8_t *img = s_w + (wave * ROWT + rt) * 16 * kStageStride;
+#pragma unroll
+                for (int j = 0; j < NBW; ++j) wq[rt][j] = *reinterpret_cast<const u32x2 *>(img + r * kStageStride + 32 * j + 8 * kb);
             }
         }
 #pragma unroll
         for (int j = 0; j < NBW; ++j) {
-            f32x4 tile = {0.0f, 0.0f, 0.0f, 0.0f};
+            u32x4 bfrag[2];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const u32x4 w = xr[j][t];
-                u32x4 bfrag;
-                bfrag.x = perm(w.y, w.x, 0x05040100u);  // (x0,x2)
-                bfrag.y = perm(w.w, w.z, 0x05040100u);  // (x4,x6)
-                bfrag.z = perm(w.y, w.x, 0x07060302u);  // (x1,x3)
-                bfrag.w = perm(w.w, w.z, 0x07060302u);  // (x5,x7)
-                uint32_t P[4];
-                decode8<DT>(t == 0 ? wq[j].x : wq[j].y, P);
-                const u32x4 afrag = {P[0], P[1], P[2], P[3]};
-                tile = mfma16<DT>(afrag, bfrag, tile);
+                bfrag[t].x = perm(w.y, w.x, 0x05040100u);  // (x0,x2)
+                bfrag[t].y = perm(w.w, w.z, 0x05040100u);  // (x4,x6)
+                bfrag[t].z = perm(w.y, w.x, 0x07060302u);  // (x1,x3)
+                bfrag[t].w = perm(w.w, w.z, 0x07060302u);  // (x5,x7)
             }
-            acc.x = __builtin_fmaf(tile.x, am[0][j], acc.x);
-            acc.y = __builtin_fmaf(tile.y, am[1][j], acc.y);
-            acc.z = __builtin_fmaf(tile.z, am[2][j], acc.z);
-            acc.w = __builtin_fmaf(tile.w, am[3][j], acc.w);
+#pragma unroll
+            for (int rt = 0; rt < ROWT; ++rt) {
+                f32x4 tile = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    uint32_t P[4];
+                    decode8<DT>(t == 0 ? wq[rt][j].x : wq[rt][j].y, P);
+                    const u32x4 afrag = {P[0], P[1], P[2], P[3]};
+                    tile = mfma16<DT>(afrag, bfrag[t], tile);
+                }
+                acc[rt].x = __builtin_fmaf(tile.x, am[rt][0][j], acc[rt].x);
+                acc[rt].y = __builtin_fmaf(tile.y, am[rt][1][j], acc[rt].y);
+                acc[rt].z = __builtin_fmaf(tile.z, am[rt][2][j], acc[rt].z);
+                acc[rt].w = __builtin_fmaf(tile.w, am[rt][3][j], acc[rt].w);
+            }
         }
     }
-    *reinterpret_cast<f32x4 *>(&s_part[wave][lane * 4]) = acc;
+#pragma unroll
+    for (int rt = 0; rt < ROWT; ++rt) *reinterpret_cast<f32x4 *>(&s_part[wave][rt][lane * 4]) = acc[rt];
     __syncthreads();
-    if (tid < 256) {
+    for (int i = tid; i < ROWT * 256; i += 512) {
+        const int rt = i >> 8, e = i & 255;
         float t = 0.0f;
 #pragma unroll
-        for (int w = 0; w < 8; ++w) t += s_part[w][tid];
-        const int l = tid >> 2, reg = tid & 3;  // D layout: col = l & 15 (activation row), row = (l >> 4) * 4 + reg (weight row)
-        const int n = l & 15, row = row0 + (l >> 4) * 4 + reg;
+        for (int w = 0; w < 8; ++w) t += s_part[w][rt][e];
+        const int l = e >> 2, reg = e & 3;  // D layout: col = l & 15 (activation row), row = (l >> 4) * 4 + reg (weight row)
+        const int n = l & 15, row = row0 + 16 * rt + (l >> 4) * 4 + reg;
         if (row < M && n < B) {
             t *= (1.0f / 12.0f);
             if (bias) t += to_f32<DT>(bias[row]);
@@ -894,21 +955,39 @@ __global__ __launch_bounds__(512) void gemm16_mfma_kernel(const uint16_t *__rest
     }
 }
 
+int g_mfma_rowt = -1;   // sweeps: force 1 or 2 row tiles per workgroup
+int g_mfma_stage = -1;  // sweeps: 0 = direct 8-byte weight loads, otherwise LDS-staged 16-byte loads
+
 template <int DT>
 int dispatch_mfma(const void *x, const uint8_t *W, const float *absmax, const void *bias, void *out, int B, int M, int K,
                   hipStream_t stream) {
     if (K % 512) return -1;
-    const unsigned blocks = (unsigned)((M + 15) / 16);
     const int units = K / 512;  // quant blocks per wave over the whole K
-#define FP4_MF(NBW)                                                                                                   \
-    hipLaunchKernelGGL((gemm16_mfma_kernel<DT, NBW>), dim3(blocks), dim3(512), 0, stream,                             \
+    // two row tiles per workgroup once that still leaves >= 256 workgroups (one per CU)
+    const int rowt = g_mfma_rowt > 0 ? g_mfma_rowt : (M >= 32 * 256 ? 2 : 1);
+    const unsigned blocks = (unsigned)((M + 16 * rowt - 1) / (16 * rowt));
+#define FP4_MF(NBW, RT)                                                                                               \
+    if (g_mfma_stage == 0) {                                                                                          \
+        hipLaunchKernelGGL((gemm16_mfma_kernel<DT, NBW, RT, false>), dim3(blocks), dim3(512), 0, stream,              \
+                           reinterpret_cast<const uint16_t *>(x), W, absmax, reinterpret_cast<const uint16_t *>(bias), \
+                           reinterpret_cast<uint16_t *>(out), B, M, K);                                               \
+        return FP4_OK;                                                                                                \
+    }                                                                                                                 \
+    hipLaunchKernelGGL((gemm16_mfma_kernel<DT, NBW, RT, true>), dim3(blocks), dim3(512), 0, stream,                   \
                        reinterpret_cast<const uint16_t *>(x), W, absmax, reinterpret_cast<const uint16_t *>(bias),    \
                        reinterpret_cast<uint16_t *>(out), B, M, K);                                                   \
     return FP4_OK
-    if (units % 8 == 0) { FP4_MF(8); }
-    if (units % 4 == 0) { FP4_MF(4); }
-    if (units % 2 == 0) { FP4_MF(2); }
-    FP4_MF(1);
+#define FP4_MF_RT(NBW)          \
+    if (rowt == 2) {            \
+        FP4_MF(NBW, 2);         \
+    } else {                    \
+        FP4_MF(NBW, 1);         \
+    }
+    if (units % 8 == 0) { FP4_MF_RT(8) }
+    if (units % 4 == 0) { FP4_MF_RT(4) }
+    if (units % 2 == 0) { FP4_MF_RT(2) }
+    FP4_MF_RT(1)
+#undef FP4_MF_RT
 #undef FP4_MF
 }
 
@@ -1023,7 +1102,12 @@ int run_generic(const void *x, const uint8_t *W, const float *absmax, const void
 }  // namespace
 
 void set_gemv_variant(int v) { g_gemv_variant = v; }
-void set_small_variant(int v) { g_small_variant = v; }
+void set_small_variant(int v) {
+    g_small_variant = v < 0 ? -1 : (v & 1);
+    g_mfma_rowt = v < 0 ? -1 : ((v >> 4) & 3);  // bits 4-5: row tiles per workgroup of the matrix-core kernel (0 = auto)
+    if (g_mfma_rowt == 0) g_mfma_rowt = -1;
+    g_mfma_stage = v < 0 ? -1 : ((v >> 8) & 1 ? 0 : 1);  // bit 8: direct (unstaged) weight loads
+}
 
 }  // namespace fp4
 
@@ -1133,9 +1217,9 @@ extern "C" int fp4_hip_gemm_small(const void *x, const uint8_t *packed, const fl
                     (K % blocksize) == 0 && (align & 15u) == 0 && M <= (int64_t(1) << 30) && K <= (int64_t(1) << 24);
     hipStream_t s = static_cast<hipStream_t>(stream);
     int rc = -1;
-    // matrix-core kernel: blocksize 64, K % 512 == 0; ties the VALU kernel at 3-4 rows, wins from 5 up (7.5 vs 11.4 us at 8), mandatory above 8
+    // matrix-core kernel: blocksize 64, K % 512 == 0; wins from 3 rows up (5.6 vs 6.8 us at 3, 6.4 vs 11.4 us at 8), mandatory above 8
     const bool mfma_ok = ok && blocksize == 64 && (K % 512) == 0;
-    const bool want_mfma = g_small_variant == 1 || (g_small_variant < 0 && B >= 5);
+    const bool want_mfma = g_small_variant == 1 || (g_small_variant < 0 && B >= 3);
     if (mfma_ok && (want_mfma || B > 8))
         rc = dtype == FP4_DTYPE_F16 ? dispatch_mfma<FP4_DTYPE_F16>(x, packed, absmax, bias, out, (int)B, (int)M, (int)K, s)
                                     : dispatch_mfma<FP4_DTYPE_BF16>(x, packed, absmax, bias, out, (int)B, (int)M, (int)K, s);
