@@ -58,6 +58,7 @@ class Lib:
         vp, i32, i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
         self.l.fp4_hip_dequantize_blockwise.argtypes = [vp, vp, vp, i32, i64, i32, i32, i32, vp]
         self.l.fp4_hip_gemv.argtypes = [vp, vp, vp, vp, vp, i64, i64, i32, i32, vp]
+        self.l.fp4_hip_gemv_partial.argtypes = [vp, vp, vp, vp, i64, i64, i32, i32, vp]
         self.l.fp4_hip_last_error.restype = ctypes.c_char_p
 
     def _check(self, rc):
@@ -71,6 +72,44 @@ class Lib:
     def gemv(self, x, packed, absmax, out, m, k, dtype=BF16):
         s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         self._check(self.l.fp4_hip_gemv(x.data_ptr(), packed.data_ptr(), absmax.data_ptr(), None, out.data_ptr(), m, k, BLOCKSIZE, dtype, s))
+
+
+def tp_ksplit_leg(lib, dist, backend, rank, world, dev, x, packed0, absmax0, barrier):
+    """N > 1 only, outside the timed region: the one place the path has a real exchange step.  One 4096x4096 weight is
+    column-sharded over the ranks (re-packed, torch_bnb_fp4.parallel.shard_cols); each rank computes its f32 partial
+    (fp4_hip_gemv_partial) and the partials meet in a 16 KiB all-reduce (RCCL over xGMI): latency-bound at this size."""
+    from torch_bnb_fp4 import parallel as par
+
+    ks = K // world
+    p_s, a_s, _ = par.shard_cols(packed0.view(-1, 1), absmax0, (M, K), BLOCKSIZE, rank, world)
+    x_s = x[rank * ks:(rank + 1) * ks].contiguous()
+    part = torch.empty(M, dtype=torch.float32, device=dev)
+    s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def reduce_():
+        if backend == "nccl":
+            dist.all_reduce(part)
+        else:  # gloo rehearsal: stage through the host
+            h = part.cpu()
+            dist.all_reduce(h)
+            part.copy_(h)
+
+    def step():
+        lib._check(lib.l.fp4_hip_gemv_partial(x_s.data_ptr(), p_s.data_ptr(), a_s.data_ptr(), part.data_ptr(), M, ks, BLOCKSIZE, BF16, s))
+        reduce_()
+
+    out = {}
+    for name, fn in (("gemv_partial_plus_allreduce_us", step), ("allreduce_16KiB_f32_us", reduce_)):
+        for _ in range(20):
+            fn()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(200):
+            fn()
+        barrier()
+        out[name] = round((time.perf_counter() - t0) / 200 * 1e6, 2)
+    out["note"] = f"K split {world} ways ({ks} columns per GPU), eager launches, backend {backend}; the collective is latency-bound"
+    return out
 
 
 def capture(fn):
@@ -244,6 +283,11 @@ def main():
 
         # ---- secondary figures (outside the timed region) ------------------------------------
         extra = {}
+        if world > 1:
+            try:
+                extra["tp_ksplit"] = tp_ksplit_leg(lib, dist, backend, rank, world, dev, x, packed[0], absmax[0], barrier)
+            except Exception as exc:  # never let the optional leg take the headline line down
+                extra["tp_ksplit"] = {"error": repr(exc)[:300]}
         if rank == 0:
             hot_dq = capture(lambda: [lib.dequant(packed[0], absmax[0], outs[0], n) for _ in range(32)])
             hot_gv = capture(lambda: [lib.gemv(x, packed[0], absmax[0], ys[0], M, K) for _ in range(128)])
