@@ -41,7 +41,7 @@ __device__ __forceinline__ float lut_entry(int idx) {
 }
 
 // STORE: 0 plain global store, 1 nontemporal builtin, 2.. buffer store with aux = STORE - 2 + ... see table in main
-template <int LOADS, int THREADS, int STORE_AUX, bool USE_BUFFER, bool LOAD_NT, int ABSMODE>
+template <int LOADS, int THREADS, int STORE_AUX, bool USE_BUFFER, bool LOAD_NT, int ABSMODE, int REMAP = 0>
 __global__ __launch_bounds__(THREADS) void dq(const uint8_t *__restrict__ packed, const float *__restrict__ absmax,
                                               void *__restrict__ out, int bs_shift, uint32_t out_bytes) {
     constexpr int kVals = 8;
@@ -50,7 +50,11 @@ __global__ __launch_bounds__(THREADS) void dq(const uint8_t *__restrict__ packed
     __shared__ float s_lut[ABSMODE == 2 ? 16 * (THREADS / 64) : 16];
     __shared__ float s_abs[kMaxAbs];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t e_base = int64_t(blockIdx.x) * kTile;
+    // REMAP 1: each XCD (blocks b, b+8, ...) owns a contiguous eighth of the tensor; REMAP 2: pairs of XCD-neighbours
+    unsigned bid = blockIdx.x;
+    if constexpr (REMAP == 1) bid = (blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8;
+    if constexpr (REMAP == 2) bid = (blockIdx.x % 8) * 2 + (blockIdx.x / 8 % 2) + (blockIdx.x / 16) * 16;
+    const int64_t e_base = int64_t(bid) * kTile;
     const int n_abs = kTile >> bs_shift;
     const float *abs_src = absmax + (e_base >> bs_shift);
     constexpr int NA = (kMaxAbs + THREADS - 1) / THREADS;
@@ -122,10 +126,10 @@ struct Variant {
     void (*launch)(const uint8_t *, const float *, void *, int64_t, hipStream_t);
 };
 
-template <int LOADS, int THREADS, int AUX, bool BUF, bool LNT, int ABSMODE>
+template <int LOADS, int THREADS, int AUX, bool BUF, bool LNT, int ABSMODE, int REMAP = 0>
 void launch(const uint8_t *p, const float *a, void *o, int64_t n, hipStream_t s) {
     constexpr int tile = THREADS * LOADS * 8;
-    hipLaunchKernelGGL((dq<LOADS, THREADS, AUX, BUF, LNT, ABSMODE>), dim3((unsigned)(n / tile)), dim3(THREADS), 0, s, p, a, o, 6,
+    hipLaunchKernelGGL((dq<LOADS, THREADS, AUX, BUF, LNT, ABSMODE, REMAP>), dim3((unsigned)(n / tile)), dim3(THREADS), 0, s, p, a, o, 6,
                        (uint32_t)(n * 2));
 }
 
@@ -163,6 +167,10 @@ int main(int argc, char **argv) {
         {"L4 T256 buf nt sc0       ", launch<4, 256, 3, true, false, 0>},
         {"L4 T256 buf nt sc0 sc1   ", launch<4, 256, 19, true, false, 0>},
         {"L4 T256 nt + nt loads    ", launch<4, 256, 2, false, true, 0>},
+        {"L4 T256 nt ntld remap-xcd", launch<4, 256, 2, false, true, 0, 1>},
+        {"L4 T256 nt ntld remap-pair", launch<4, 256, 2, false, true, 0, 2>},
+        {"L2 T256 nt ntld remap-xcd", launch<2, 256, 2, false, true, 0, 1>},
+        {"L8 T256 nt ntld remap-xcd", launch<8, 256, 2, false, true, 0, 1>},
         {"L4 T256 nt ntld wave-sync", launch<4, 256, 2, false, true, 2>},
         {"L8 T256 nt ntld wave-sync", launch<8, 256, 2, false, true, 2>},
         {"L4 T128 nt ntld wave-sync", launch<4, 128, 2, false, true, 2>},
