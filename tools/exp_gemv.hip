@@ -173,6 +173,8 @@ int main(int argc, char **argv) {
         {"regx it4", (1 << 24) | 4},                  {"regx it8", (1 << 24) | 8},
         {"regx ks2 it1", (1 << 24) | (2 << 8) | 1}, {"regx ks2 it2", (1 << 24) | (2 << 8) | 2}, {"regx ks2 it4", (1 << 24) | (2 << 8) | 4},
         {"regx ks1 it1", (1 << 24) | (1 << 8) | 1}, {"regx ks1 it2", (1 << 24) | (1 << 8) | 2},
+        {"regx 8waves it1", (1 << 24) | (8 << 8) | 1}, {"regx 8waves it2", (1 << 24) | (8 << 8) | 2},
+        {"regx 8waves it4", (1 << 24) | (8 << 8) | 4},
         {"default heuristic", -1},
     };
     for (auto &v : variants) {

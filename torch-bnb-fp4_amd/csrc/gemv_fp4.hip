@@ -246,12 +246,12 @@ __global__ __launch_bounds__(WAVES * 64) void gemv16_kernel(const uint16_t *__re
 //   * a workgroup handles ITERS row-pairs per row group; every weight load of the workgroup is issued
 //     before the first dot2; per (row, band) partial sums meet in LDS (KSPLIT floats per row), one
 //     barrier at the very end; with KSPLIT == 1 nothing is shared at all.
-template <int DT, int KSPLIT, int G, int ITERS>
-__global__ __launch_bounds__(256) void gemv16_regx_kernel(const uint16_t *__restrict__ x, const uint8_t *__restrict__ W,
+template <int DT, int KSPLIT, int G, int ITERS, int WAVES = 4>
+__global__ __launch_bounds__(WAVES * 64) void gemv16_regx_kernel(const uint16_t *__restrict__ x, const uint8_t *__restrict__ W,
                                                           const float *__restrict__ absmax,
                                                           const uint16_t *__restrict__ bias, uint16_t *__restrict__ out,
                                                           int M, int K, int bs_shift, int out_f32) {
-    constexpr int RG = 4 / KSPLIT;               // row-pair groups per workgroup
+    constexpr int RG = WAVES / KSPLIT;           // row-pair groups per workgroup
     constexpr int kRowsPerBlock = 2 * RG * ITERS;
     __shared__ float s_part[kRowsPerBlock][KSPLIT];
     const int tid = threadIdx.x;
@@ -1034,12 +1034,12 @@ int dispatch_small(const void *x, const uint8_t *W, const float *absmax, const v
     return -1;
 }
 
-template <int DT, int KSPLIT, int G, int ITERS>
+template <int DT, int KSPLIT, int G, int ITERS, int WAVES = 4>
 int launch_regx(const void *x, const uint8_t *W, const float *absmax, const void *bias, void *out, int M, int K, int bs_shift,
                 int out_f32, hipStream_t stream) {
-    constexpr int rows_per_block = 2 * (4 / KSPLIT) * ITERS;
+    constexpr int rows_per_block = 2 * (WAVES / KSPLIT) * ITERS;
     const unsigned blocks = (unsigned)((M + rows_per_block - 1) / rows_per_block);
-    hipLaunchKernelGGL((gemv16_regx_kernel<DT, KSPLIT, G, ITERS>), dim3(blocks), dim3(256), 0, stream,
+    hipLaunchKernelGGL((gemv16_regx_kernel<DT, KSPLIT, G, ITERS, WAVES>), dim3(blocks), dim3(WAVES * 64), 0, stream,
                        reinterpret_cast<const uint16_t *>(x), W, absmax, reinterpret_cast<const uint16_t *>(bias),
                        reinterpret_cast<uint16_t *>(out), M, K, bs_shift, out_f32);
     return FP4_OK;
@@ -1051,6 +1051,11 @@ template <int DT>
 int dispatch_regx(int iters, int ks_override, const void *x, const uint8_t *W, const float *absmax, const void *bias, void *out,
                   int M, int K, int bs_shift, int out_f32, hipStream_t stream) {
     const int C = K >> 5;
+    if (ks_override == 8 && C > 64 && C <= 128) {  // sweep hook: 8 waves per workgroup (two row-pair groups)
+        if (iters == 1) return launch_regx<DT, 4, 1, 1, 8>(x, W, absmax, bias, out, M, K, bs_shift, out_f32, stream);
+        if (iters == 2) return launch_regx<DT, 4, 1, 2, 8>(x, W, absmax, bias, out, M, K, bs_shift, out_f32, stream);
+        if (iters == 4) return launch_regx<DT, 4, 1, 4, 8>(x, W, absmax, bias, out, M, K, bs_shift, out_f32, stream);
+    }
     int ks = C <= 32 ? 1 : (C <= 64 ? 2 : 4);
     if (ks_override == 1 || ks_override == 2 || ks_override == 4) ks = ks_override;
     const int need = (C + 32 * ks - 1) / (32 * ks);
