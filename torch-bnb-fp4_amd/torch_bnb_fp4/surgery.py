@@ -25,11 +25,13 @@ log = logging.getLogger(__name__)
 def swap_linear_with_bnb_linear(linear: nn.Linear, dtype=torch.float16) -> LinearFP4:
     """New (still dense) ``LinearFP4`` holding clones of ``linear``'s weight and bias; it quantises
     when moved to a GPU (reference :717-747)."""
+    # built on the meta device: nn.Linear.__init__ would otherwise allocate and randomly initialise a full dense
+    # weight on the CPU only to have it replaced (18 s of a 7B model's 224 layers)
     fp4 = LinearFP4(input_features=linear.in_features, output_features=linear.out_features,
-                    bias=linear.bias is not None, compute_dtype=dtype)
+                    bias=linear.bias is not None, compute_dtype=dtype, device="meta")
     fp4.weight = Params4bit(linear.weight.data.clone().detach(), False, None, fp4.blocksize, "fp4")
     if linear.bias is not None:
-        fp4.bias.data = linear.bias.data.clone().detach()
+        fp4.bias = nn.Parameter(linear.bias.data.clone().detach(), requires_grad=False)
     fp4.requires_grad_(False)
     return fp4
 
