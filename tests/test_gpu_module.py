@@ -216,3 +216,22 @@ def test_hip_graph_capture_and_replay_of_the_linear_shell():
         g.replay()
         torch.cuda.synchronize()
         assert torch.equal(out, step(new_x))
+
+
+def test_fuse_rows_is_bit_identical_to_separate_layers():
+    P = pkg()
+    torch.manual_seed(11)
+    q, k, v = (P.TorchFP4Linear(P.swap_linear_with_bnb_linear(nn.Linear(1024, m).to(dev())).to(dev())) for m in (1024, 256, 256))
+    qkv = P.TorchFP4Linear.fuse([q, k, v], name="qkv")
+    assert qkv.out_features == 1536 and qkv.in_features == 1024
+    for dtype in (torch.bfloat16, torch.float16, torch.float32):
+        x = torch.randn(1, 1, 1024, device=dev(), dtype=dtype)
+        for lyr in (q, k, v, qkv):
+            lyr.quant_data.compute_dtype_set = False  # let every layer follow the activation dtype of this round
+        want = torch.cat([q(x), k(x), v(x)], dim=-1)
+        assert torch.equal(qkv(x), want)
+        xb = torch.randn(5, 1024, device=dev(), dtype=dtype)
+        got, ref = qkv(xb), torch.cat([q(xb), k(xb), v(xb)], dim=-1)
+        assert (got.float() - ref.float()).abs().max().item() <= 2e-2 * (1 + ref.float().abs().max().item())
+    with pytest.raises(ValueError):
+        P.TorchFP4Linear.fuse([q, P.TorchFP4Linear(P.swap_linear_with_bnb_linear(nn.Linear(512, 64).to(dev())).to(dev()))])

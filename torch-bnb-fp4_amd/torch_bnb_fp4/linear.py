@@ -55,6 +55,28 @@ class TorchFP4Linear(nn.Module):
                 f"bias={self.lin[0].bias is not None}" + (f", dtype={dt})" if hasattr(self, "quant_data") else ")"))
 
     @classmethod
+    def fuse(cls, layers, name: str = "") -> "TorchFP4Linear":
+        """One layer computing ``cat([l(x) for l in layers], -1)`` in a single launch (fused QKV / gate-up projections):
+        rows of an FP4 weight are independent and ``in_features % blocksize == 0``, so the packed bytes, scales and
+        biases are simply concatenated.  Bit-identical to the separate layers on the GEMV path."""
+        from .nn import LinearFP4, Params4bit, QuantState
+        from .parallel import concat_rows
+
+        qds = [l.quant_data for l in layers]
+        bs = qds[0].blocksize
+        if any(q.blocksize != bs or q.N != qds[0].N for q in qds):
+            raise ValueError("fuse() needs layers with the same in_features and blocksize")
+        if len({q.bias is None for q in qds}) != 1:
+            raise ValueError("fuse() needs either every layer or no layer to carry a bias")
+        packed, absmax, (M, K) = concat_rows([(q.A, q.absmax, (q.M, q.N)) for q in qds], bs)
+        shell = LinearFP4(K, M, bias=qds[0].bias is not None, device="meta")
+        state = QuantState(absmax, (M, K), qds[0].code, bs, qds[0].quant_state.dtype)
+        shell._parameters["weight"] = Params4bit(packed, False, state, bs, "fp4")
+        if qds[0].bias is not None:
+            shell._parameters["bias"] = nn.Parameter(torch.cat([q.bias.reshape(-1) for q in qds]), requires_grad=False)
+        return cls(shell, use_codebook_dequant=layers[0].use_codebook_dequant, name=name)
+
+    @classmethod
     def from_linear(cls, linear, use_codebook_dequant: bool = False, name: str = "") -> "TorchFP4Linear":
         """Wrap an already-quantised FP4 layer (note the reference's default of ``False`` here, :699)."""
         return cls(linear, use_codebook_dequant=use_codebook_dequant, name=name)
