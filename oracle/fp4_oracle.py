@@ -300,7 +300,7 @@ def quantize_fp4(w, blocksize: int = 64):
     padded[:n] = w
     blk = padded.reshape(nblocks, blocksize)
     absmax = np.abs(blk).max(axis=1).astype(np.float32)
-    with np.errstate(divide="ignore", invalid="ignore"):
+    with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
         inv = (np.float32(1.0) / absmax).astype(np.float32)
         xn = (blk * inv[:, None]).astype(np.float32)
     mag = np.abs(xn)

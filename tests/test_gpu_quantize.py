@@ -30,6 +30,62 @@ def test_quantize_matches_oracle(dtype, bs):
     assert np.array_equal(got, want_p)
 
 
+def _check(w_t, bs):
+    packed, absmax = hipabi.quantize(w_t.to(dev()), bs)
+    want_p, want_a = o.quantize_fp4(w_t.float().cpu().numpy().reshape(-1), bs)
+    np.testing.assert_array_equal(absmax.cpu().numpy(), want_a)  # NaN == NaN here
+    bad = np.flatnonzero(packed.cpu().numpy() != want_p)
+    assert bad.size == 0, (bad[:8], packed.cpu().numpy()[bad[:8]], want_p[bad[:8]])
+
+
+def test_quantize_threshold_neighbourhoods():
+    """absmax 1 makes x == w, so every threshold, its two f32 neighbours, both signs, -0.0 and the smallest
+    denormals hit the ranking rule directly (the kernel ranks on bit patterns, the oracle with float compares)."""
+    t = np.asarray(o.QUANT_THRESHOLDS, dtype=np.float32)
+    vals = np.concatenate([t, np.nextafter(t, np.float32(2)), np.nextafter(t, np.float32(0)),
+                           np.asarray([0.0, 1e-45, 1e-40, 1.1754944e-38, 0.99999994], np.float32)])
+    vals = np.concatenate([vals, -vals]).astype(np.float32)
+    blocks = []
+    for i in range(0, vals.size, 63):
+        chunk = np.zeros(64, np.float32)
+        c = vals[i : i + 63]
+        chunk[: c.size] = c
+        chunk[63] = 1.0 if (i // 63) % 2 == 0 else -1.0
+        blocks.append(chunk)
+    _check(torch.from_numpy(np.concatenate(blocks)), 64)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("order", ["sorted", "shuffled"])
+def test_quantize_every_16bit_pattern(dtype, order):
+    """All 65536 bit patterns of the input type as weights - subnormals, infinities and NaNs included - once sorted by
+    magnitude (blocks of near-equal values, subnormal / infinite / NaN absmax) and once shuffled."""
+    bits = torch.arange(-32768, 32768, dtype=torch.int32).to(torch.int16)
+    w = bits.view(dtype)
+    if order == "sorted":
+        w = w[torch.argsort((bits.to(torch.int32) & 0x7FFF), stable=True)]
+    else:
+        w = w[torch.randperm(w.numel(), generator=torch.Generator().manual_seed(3))]
+    for bs in (64, 32, 256):
+        _check(w, bs)
+
+
+def test_quantize_nonfinite_scale_blocks():
+    """f32 blocks whose absmax is subnormal (1/absmax = inf, so 0*inf = NaN), infinite or NaN."""
+    rng = np.random.default_rng(5)
+    w = rng.standard_normal(64 * 8).astype(np.float32)
+    w[0:64] = rng.choice(np.asarray([0.0, 1e-39, -1e-39, 5e-40, -3e-45, -0.0], np.float32), 64)
+    w[64:128] *= np.float32(1e-41)
+    w[130] = np.inf
+    w[200] = -np.inf
+    w[201] = 0.0
+    w[260] = np.nan
+    w[330] = 3e38
+    w[331] = -1e-45
+    _check(torch.from_numpy(w), 64)
+    _check(torch.from_numpy(w), 256)
+
+
 def test_quantize_full_matrix_and_roundtrip():
     M = K = 4096
     g = torch.Generator(device="cpu").manual_seed(0)

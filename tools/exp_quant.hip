@@ -1,0 +1,276 @@
+// Where does the FP4 quantiser's time go?  Variants of csrc/quantize_fp4.hip's kernel (bf16 input, blocksize 64 fixed) timed
+// with the bench's launch structure (HIP graph of R launches, inputs rotating over > 1 GB so every launch is HBM-cold).
+// hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off tools/exp_quant.hip -o /tmp/exp_quant
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CK(x)                                                                             \
+    do {                                                                                  \
+        hipError_t e_ = (x);                                                              \
+        if (e_ != hipSuccess) {                                                           \
+            printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); \
+            exit(1);                                                                      \
+        }                                                                                 \
+    } while (0)
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+enum : int { F_DPP = 1, F_NOQUANT = 2, F_NTLOAD = 4, F_NOABSMAX = 8, F_NTSTORE = 16, F_FLOATCMP = 32, F_NOREDUCE = 64, F_RCP = 128 };
+
+__device__ __forceinline__ uint32_t q_int(float x) {
+    const uint32_t xb = __builtin_bit_cast(uint32_t, x);
+    const uint32_t a = xb & 0x7FFFFFFFu;
+    auto gt = [a](float tf) -> uint32_t {
+        uint32_t d = __builtin_bit_cast(uint32_t, tf) - a;
+        asm volatile("" : "+v"(d));
+        return d >> 31;
+    };
+    const uint32_t rank = gt(0.00260417f) + gt(0.0859375f) + gt(0.20833333f) + gt(0.29166667f) + gt(0.4166667f) + gt(0.583333f) + gt(0.8333333f);
+    const uint32_t code = rank ^ ((rank & 2u) << 1);
+    return code | (((xb & (0u - a)) >> 28) & 8u);
+}
+__device__ __forceinline__ uint32_t q_float(float x) {
+    const float a = __builtin_fabsf(x);
+    const uint32_t rank = (a > 0.00260417f) + (a > 0.0859375f) + (a > 0.20833333f) + (a > 0.29166667f) + (a > 0.4166667f) + (a > 0.583333f) + (a > 0.8333333f);
+    const uint32_t code = rank ^ ((rank & 2u) << 1);
+    return code | (x < 0.0f ? 8u : 0u);
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_max(float v) {
+    const int moved = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false);
+    return __builtin_fmaxf(v, __builtin_bit_cast(float, moved));
+}
+
+template <int THREADS, int ITEMS, int FLAGS>
+__global__ __launch_bounds__(THREADS) void quant(const u32x4 *__restrict__ w, uint32_t *__restrict__ packed, float *__restrict__ absmax) {
+    const int tid = threadIdx.x;
+    const int64_t g0 = int64_t(blockIdx.x) * (THREADS * ITEMS) + tid;  // 8-element group index of item 0
+    u32x4 raw[ITEMS];
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) raw[it] = (FLAGS & F_NTLOAD) ? __builtin_nontemporal_load(w + g0 + it * THREADS) : w[g0 + it * THREADS];
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[2 * i] = __builtin_bit_cast(float, raw[it][i] << 16);
+            v[2 * i + 1] = __builtin_bit_cast(float, raw[it][i] & 0xFFFF0000u);
+        }
+        float m = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) m = __builtin_fmaxf(m, __builtin_fabsf(v[i]));
+        if (!(FLAGS & F_NOREDUCE)) {
+            if (FLAGS & F_DPP) {
+                m = dpp_max<0xB1>(m);   // quad_perm [1,0,3,2]
+                m = dpp_max<0x4E>(m);   // quad_perm [2,3,0,1]
+                m = dpp_max<0x141>(m);  // row_half_mirror
+            } else {
+                volatile int lanes = 8;
+                const int l = lanes;
+                for (int mask = 1; mask < l && mask < 64; mask <<= 1) m = __builtin_fmaxf(m, __shfl_xor(m, mask));
+            }
+        }
+        const int64_t g = g0 + it * THREADS;
+        if (!(FLAGS & F_NOABSMAX))
+            if ((tid & 7) == 0) absmax[g >> 3] = m;
+        const float inv = (FLAGS & F_RCP) ? __builtin_amdgcn_rcpf(m) : (m > 0.0f ? 1.0f / m : 0.0f);
+        uint32_t word = 0;
+        if (FLAGS & F_NOQUANT) {
+            word = __builtin_bit_cast(uint32_t, v[0] * inv) ^ raw[it][1] ^ raw[it][2] ^ raw[it][3];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const uint32_t q = (FLAGS & F_FLOATCMP) ? q_float(v[i] * inv) : q_int(v[i] * inv);
+                word |= q << (8 * (i >> 1) + ((i & 1) ? 0 : 4));
+            }
+        }
+        if (FLAGS & F_NTSTORE)
+            __builtin_nontemporal_store(word, packed + g);
+        else
+            packed[g] = word;
+    }
+}
+
+
+// ---- variant 2: bit-plane ranking (7 subtracts + 5 v_bitop3 + 4 v_alignbit per element), optional persistent loop with a
+// one-tile prefetch so one wave's arithmetic overlaps the next tile's HBM latency
+enum : int { P_PLANES = 1, P_PERSIST = 2, P_NT = 4, P_NOLOAD = 8, P_NOSTORE = 16 };
+__device__ __forceinline__ uint32_t push(uint32_t acc, uint32_t plane) { return __builtin_amdgcn_alignbit(acc, plane, 31); }
+
+__device__ __forceinline__ uint32_t nibble_planes(uint32_t acc, uint32_t sign_src, float a_f) {
+    const uint32_t a = __builtin_bit_cast(uint32_t, a_f);  // |x| bits
+    auto diff = [a](float tf) -> uint32_t { return __builtin_bit_cast(uint32_t, tf) - a; };  // bit 31 = (a > t)
+    const uint32_t d0 = diff(0.00260417f), d1 = diff(0.0859375f), d2 = diff(0.20833333f), d3 = diff(0.29166667f);
+    const uint32_t d4 = diff(0.4166667f), d5 = diff(0.583333f), d6 = diff(0.8333333f);
+    const uint32_t nz = 0u - a;  // bit 31 = (a != 0)
+    const uint32_t c0 = d0 ^ d1 ^ d2 ^ d3 ^ d4 ^ d5 ^ d6;  // rank parity
+    const uint32_t c1 = d1 & (~d3 | d5);                   // rank in {2,3,6,7}
+    const uint32_t c2 = d3 ^ c1;                           // code bit 2 = rank bit 2 ^ rank bit 1
+    acc = push(acc, sign_src & nz);
+    acc = push(acc, c2);
+    acc = push(acc, c1);
+    return push(acc, c0);
+}
+
+template <int FLAGS>
+__device__ __forceinline__ void quant_tile(const u32x4 raw, int64_t g, int tid, uint32_t *__restrict__ packed, float *__restrict__ absmax) {
+    uint32_t sgn[8];
+    float av[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        sgn[2 * i] = raw[i] << 16;
+        sgn[2 * i + 1] = raw[i];
+        av[2 * i] = __builtin_bit_cast(float, sgn[2 * i] & 0x7FFFFFFFu);
+        av[2 * i + 1] = __builtin_bit_cast(float, raw[i] & 0x7FFF0000u);
+    }
+    float m = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) m = __builtin_fmaxf(m, av[i]);
+    m = dpp_max<0xB1>(m);
+    m = dpp_max<0x4E>(m);
+    m = dpp_max<0x141>(m);
+    if (!(FLAGS & P_NOSTORE))
+        if ((tid & 7) == 0) absmax[g >> 3] = m;
+    const float inv = m > 0.0f ? 1.0f / m : 0.0f;
+    uint32_t word = 0;
+    if (FLAGS & P_PLANES) {
+        constexpr int order[8] = {6, 7, 4, 5, 2, 3, 0, 1};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) word = nibble_planes(word, sgn[order[k]], av[order[k]] * inv);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const uint32_t q = q_int(__builtin_bit_cast(float, __builtin_bit_cast(uint32_t, av[i]) | (sgn[i] & 0x80000000u)) * inv);
+            word |= q << (8 * (i >> 1) + ((i & 1) ? 0 : 4));
+        }
+    }
+    if (FLAGS & P_NOSTORE) {
+        if (word == 0x12345u) packed[g] = word;
+    } else if (FLAGS & P_NT)
+        __builtin_nontemporal_store(word, packed + g);
+    else
+        packed[g] = word;
+}
+
+template <int THREADS, int FLAGS>
+__global__ __launch_bounds__(THREADS) void quant2(const u32x4 *__restrict__ w, uint32_t *__restrict__ packed, float *__restrict__ absmax, int ntiles) {
+    const int tid = threadIdx.x;
+    if (FLAGS & P_PERSIST) {
+        int t = blockIdx.x;
+        u32x4 cur = (FLAGS & P_NT) ? __builtin_nontemporal_load(w + int64_t(t) * THREADS + tid) : w[int64_t(t) * THREADS + tid];
+        while (true) {
+            const int tn = t + gridDim.x;
+            const int tl = tn < ntiles ? tn : t;  // clamped: the load stays unconditional
+            const u32x4 nxt = (FLAGS & P_NT) ? __builtin_nontemporal_load(w + int64_t(tl) * THREADS + tid) : w[int64_t(tl) * THREADS + tid];
+            quant_tile<FLAGS>(cur, int64_t(t) * THREADS + tid, tid, packed, absmax);
+            if (tn >= ntiles) break;
+            cur = nxt;
+            t = tn;
+        }
+    } else {
+        const int64_t g = int64_t(blockIdx.x) * THREADS + tid;
+        u32x4 raw;
+        if (FLAGS & P_NOLOAD) {
+            const uint32_t h = uint32_t(g) * 0x9E3779B1u;
+            raw = u32x4{h, h ^ 0x12345678u, h * 3u, h + 0x3c003c00u};
+        } else {
+            raw = (FLAGS & P_NT) ? __builtin_nontemporal_load(w + g) : w[g];
+        }
+        quant_tile<FLAGS>(raw, g, tid, packed, absmax);
+    }
+}
+
+int main() {
+    const int RW = 24;
+    const int64_t n = 4096ll * 4096;
+    std::vector<void *> w(RW), p(RW), a(RW);
+    for (int i = 0; i < RW; ++i) {
+        CK(hipMalloc(&w[i], n * 2));
+        CK(hipMalloc(&p[i], n / 2));
+        CK(hipMalloc(&a[i], n / 64 * 4));
+        CK(hipMemset(w[i], 0x3c + i, n * 2));
+    }
+    hipStream_t s;
+    CK(hipStreamCreate(&s));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    const int R = 2 * RW;
+    auto run = [&](const char *name, auto launch) {
+        hipGraph_t g;
+        hipGraphExec_t ge;
+        CK(hipStreamBeginCapture(s, hipStreamCaptureModeGlobal));
+        for (int i = 0; i < R; ++i) launch(i % RW);
+        CK(hipStreamEndCapture(s, &g));
+        CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+        for (int k = 0; k < 2; ++k) CK(hipGraphLaunch(ge, s));
+        CK(hipStreamSynchronize(s));
+        std::vector<float> t;
+        for (int rep = 0; rep < 7; ++rep) {
+            CK(hipEventRecord(e0, s));
+            CK(hipGraphLaunch(ge, s));
+            CK(hipEventRecord(e1, s));
+            CK(hipEventSynchronize(e1));
+            float ms;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            t.push_back(ms * 1e3f / R);
+        }
+        std::sort(t.begin(), t.end());
+        const double bytes = n * 2.0 + n / 2 + n / 64 * 4;
+        printf("%-64s %8.2f us/launch -> %7.1f GB/s\n", name, t[t.size() / 2], bytes / t[t.size() / 2] / 1e3);
+        fflush(stdout);
+        CK(hipGraphExecDestroy(ge));
+        CK(hipGraphDestroy(g));
+    };
+#define RUN(T, I, F)                                                                                                           \
+    run("threads=" #T " items=" #I " flags=" #F, [&](int i) {                                                                   \
+        hipLaunchKernelGGL((quant<T, I, (F)>), dim3(unsigned(n / 8 / (T * I))), dim3(T), 0, s, (const u32x4 *)w[i], (uint32_t *)p[i], \
+                           (float *)a[i]);                                                                                      \
+    })
+    RUN(512, 1, F_FLOATCMP);
+    RUN(512, 1, 0);
+    RUN(512, 1, F_DPP);
+    RUN(512, 1, F_DPP | F_NOQUANT);
+    RUN(512, 1, F_DPP | F_NOABSMAX);
+    RUN(512, 1, F_DPP | F_NOREDUCE);
+    RUN(512, 1, F_DPP | F_RCP);
+    RUN(512, 1, F_DPP | F_NTLOAD);
+    RUN(512, 1, F_DPP | F_NTLOAD | F_NTSTORE);
+    RUN(256, 1, F_DPP);
+    RUN(256, 2, F_DPP);
+    RUN(256, 4, F_DPP);
+    RUN(256, 2, F_DPP | F_NTLOAD);
+    RUN(256, 4, F_DPP | F_NTLOAD);
+    RUN(256, 4, F_DPP | F_NTLOAD | F_NTSTORE);
+    RUN(256, 8, F_DPP | F_NTLOAD);
+    RUN(256, 4, F_DPP | F_NTLOAD | F_NOQUANT);
+    RUN(256, 4, F_DPP | F_NTLOAD | F_NOQUANT | F_NOABSMAX);
+    RUN(1024, 1, F_DPP);
+#define RUN2(T, F, GRID)                                                                                                        \
+    run("v2 threads=" #T " flags=" #F " grid=" #GRID, [&](int i) {                                                                \
+        const int ntiles = int(n / 8 / T);                                                                                        \
+        const int grid = (GRID) > 0 ? (GRID) : ntiles;                                                                            \
+        hipLaunchKernelGGL((quant2<T, (F)>), dim3(grid), dim3(T), 0, s, (const u32x4 *)w[i], (uint32_t *)p[i], (float *)a[i], ntiles); \
+    })
+    RUN2(256, P_PLANES | P_NOLOAD, 0);
+    RUN2(256, P_PLANES | P_NOLOAD | P_NOSTORE, 0);
+    RUN2(256, P_PLANES | P_NOSTORE, 0);
+    RUN2(512, 0, 0);
+    RUN2(512, P_PLANES, 0);
+    RUN2(256, P_PLANES, 0);
+    RUN2(256, P_PLANES | P_PERSIST, 256 * 4);
+    RUN2(256, P_PLANES | P_PERSIST, 256 * 8);
+    RUN2(256, P_PLANES | P_PERSIST, 256 * 6);
+    RUN2(256, P_PERSIST, 256 * 8);
+    RUN2(256, P_PLANES | P_PERSIST | P_NT, 256 * 8);
+    RUN2(512, P_PLANES | P_PERSIST, 256 * 4);
+    RUN2(512, P_PLANES | P_PERSIST, 256 * 2);
+    RUN2(1024, P_PLANES | P_PERSIST, 256 * 2);
+    RUN2(128, P_PLANES | P_PERSIST, 256 * 16);
+    RUN2(64, P_PLANES | P_PERSIST, 256 * 32);
+    return 0;
+}

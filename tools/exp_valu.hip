@@ -67,6 +67,31 @@ __global__ __launch_bounds__(256) void k(uint32_t *out, uint32_t seed) {
                 asm volatile("v_pk_mul_f16 %0, %1, %2" : "=v"(r) : "v"(a[i]), "v"(b));
                 a[i] = __builtin_bit_cast(uint32_t, r);
             }
+            if constexpr (OP == 20) asm volatile("v_sub_u32 %0, %1, %0" : "+v"(a[i]) : "v"(b));
+            if constexpr (OP == 21) asm volatile("v_lshrrev_b32 %0, 1, %0" : "+v"(a[i]));
+            if constexpr (OP == 22) asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+            if constexpr (OP == 23) asm volatile("v_alignbit_b32 %0, %0, %1, 31" : "+v"(a[i]) : "v"(b));
+            if constexpr (OP == 24) asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(a[i]) : "v"(b), "v"(c));
+            if constexpr (OP == 25) asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(a[i]) : "v"(b));
+            if constexpr (OP == 26) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(f[i]) : "v"(b), "v"(c));
+            if constexpr (OP == 27) {
+                f32x2 v = {f[i], f[(i + 1) & 15]};
+                f32x2 r;
+                asm volatile("v_pk_add_f32 %0, %1, %1" : "=v"(r) : "v"(v));
+                f[i] = r.x;
+            }
+            if constexpr (OP == 28) asm volatile("v_lshl_or_b32 %0, %0, 4, %1" : "+v"(a[i]) : "v"(b));
+            if constexpr (OP == 29) asm volatile("v_cmp_lt_u32 vcc, %1, %0\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc" : "+v"(a[i]) : "v"(b) : "vcc");
+            if constexpr (OP == 30) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(f[i]) : "v"(b));
+            if constexpr (OP == 31) asm volatile("v_pk_sub_u16 %0, %1, %0" : "+v"(a[i]) : "v"(b));
+            if constexpr (OP == 32) asm volatile("v_pk_lshrrev_b16 %0, 15, %0" : "+v"(a[i]));
+            if constexpr (OP == 33) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+            if constexpr (OP == 34) asm volatile("v_or3_b32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+            if constexpr (OP == 35) asm volatile("v_sub_u32 %0, %1, %0" : "+v"(a[i]) : "s"(seed));
+            if constexpr (OP == 36) asm volatile("v_sub_u32 %0, 0x3e955555, %0" : "+v"(a[i]));
+            if constexpr (OP == 37) asm volatile("v_max_f32 %0, |%0|, |%1|" : "+v"(f[i]) : "v"(b));
+            if constexpr (OP == 38) asm volatile("v_bfi_b32 %0, %1, %0, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+            if constexpr (OP == 39) asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
             if constexpr (OP == 11) {  // v_cvt_f32_f16 (SDWA-free) + fma
                 f[i] = __builtin_fmaf(float(__builtin_bit_cast(f16x2, a[i]).x), f[i], 1.0f);
             }
@@ -100,6 +125,30 @@ void run(const char *name, int instr_per_step, uint32_t *out) {
 int main() {
     uint32_t *out;
     CK(hipMalloc(&out, 4096));
+    if (getenv("EXP_VALU_INT")) {
+        run<14>("v_and_b32", 1, out);
+        run<20>("v_sub_u32", 1, out);
+        run<35>("v_sub_u32 (sgpr operand)", 1, out);
+        run<36>("v_sub_u32 (literal operand)", 1, out);
+        run<21>("v_lshrrev_b32", 1, out);
+        run<33>("v_xor_b32", 1, out);
+        run<22>("v_add3_u32", 1, out);
+        run<34>("v_or3_b32", 1, out);
+        run<28>("v_lshl_or_b32", 1, out);
+        run<23>("v_alignbit_b32", 1, out);
+        run<24>("v_bitop3_b32", 1, out);
+        run<38>("v_bfi_b32", 1, out);
+        run<39>("v_mad_u32_u24", 1, out);
+        run<25>("v_bcnt_u32_b32", 1, out);
+        run<29>("v_cmp_lt_u32 + v_addc_co (2 instr)", 2, out);
+        run<31>("v_pk_sub_u16", 1, out);
+        run<32>("v_pk_lshrrev_b16", 1, out);
+        run<30>("v_mul_f32", 1, out);
+        run<37>("v_max_f32 |a|,|b|", 1, out);
+        run<26>("v_max3_f32", 1, out);
+        run<27>("v_pk_add_f32", 1, out);
+        return 0;
+    }
     run<0>("v_fma_f32", 1, out);
     run<1>("v_perm_b32", 1, out);
     run<2>("v_dot2c_f32_bf16", 1, out);

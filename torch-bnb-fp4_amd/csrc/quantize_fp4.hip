@@ -6,10 +6,10 @@
 //   absmax = max|w| over the block;  x = w * (1/absmax) in f32;
 //   magnitude rank = #{t in thresholds : |x| > t};  code = rankmap[rank] | (x < 0 ? 8 : 0);
 //   even element -> high nibble.
-// HBM-bound (2-4 B read, 0.5625 B written per element).  Each lane owns 8 consecutive elements
-// (one 16-byte load for 16-bit inputs) and emits one packed dword, so loads and stores are both
-// fully coalesced; the block maximum is a butterfly over the bs/8 lanes that share a block
-// (cross-wave through LDS only for blocksize > 512).
+// 2-4 B read and 0.5625 B written per element; the ranking arithmetic is what has to be kept off the
+// critical path (see encode8).  Each lane owns 8 consecutive elements (one 16-byte load for 16-bit inputs) and emits
+// one packed dword, so loads and stores are both fully coalesced; the block maximum is a butterfly over
+// the bs/8 lanes that share a block (DPP up to 16 lanes, cross-wave through LDS only for blocksize > 512).
 #include "fp4_common.h"
 
 namespace fp4 {
@@ -18,16 +18,80 @@ namespace {
 
 constexpr int kQThreads = 512;  // 4096 elements per workgroup = the largest supported blocksize
 
-__device__ __forceinline__ uint32_t quantize_one(float x) {
-    const float a = __builtin_fabsf(x);
-    // midpoints between neighbouring magnitudes of {0, 1/192, 1/6, 1/4, 1/3, 1/2, 2/3, 1}; strict '>'
-    int rank = (a > 0.00260417f) + (a > 0.0859375f) + (a > 0.20833333f) + (a > 0.29166667f) + (a > 0.4166667f) +
-               (a > 0.583333f) + (a > 0.8333333f);
-    // rank -> 3-bit code {0,1,6,7,4,5,2,3}, one nibble each
-    const uint32_t code = (0x32547610u >> (4 * rank)) & 7u;
-    return code | (x < 0.0f ? 8u : 0u);
+// Ranking.  Thresholds = midpoints between neighbouring magnitudes of {0, 1/192, 1/6, 1/4, 1/3, 1/2, 2/3, 1}, strict '>'
+// (the published bitsandbytes rule, see oracle/fp4_oracle.py).  Done naively (seven float compares per element, ~70
+// instructions with the SGPR-mask round trips) the kernel is VALU-bound at a third of the HBM rate, so the rank comes
+// from a 71-entry table in LDS instead, exactly:
+//   * for non-negative floats the unsigned order of the BIT PATTERNS is the numeric order;
+//   * bucket = bits >> 20 (exponent + 3 mantissa bits); every threshold falls in a different bucket, so inside a bucket
+//     the rank is `rank_lo`, plus one if the low 20 bits exceed that bucket's threshold;
+//   * the entry is (7 - rank_lo) << 28 | threshold_low20 (0xFFFFF if the bucket has none): subtracting the element's low
+//     20 bits borrows out of bit 28 exactly when they exceed the threshold, leaving r = 7 - rank in bits 30..28;
+//   * |x| is clamped from below to the first bucket (everything there is rank 0), 1.0 is the last bucket.
+// The sign of x goes into bit 31 with one v_bitop3, one v_alignbit pushes the nibble [sign r2 r1 r0] into the packed word
+// and three bitwise ops on the finished word turn all eight r's into codes (rank -> code is {0,1,6,7,4,5,2,3}, i.e.
+// code = [r2^r1, ~r1, ~r0]).  ~13 issue slots per element; rates: profiles/r01_f_exp_valu_int_rates.txt.
+constexpr uint32_t kThresholdBits[7] = {
+    __builtin_bit_cast(uint32_t, 0.00260417f), __builtin_bit_cast(uint32_t, 0.0859375f),
+    __builtin_bit_cast(uint32_t, 0.20833333f), __builtin_bit_cast(uint32_t, 0.29166667f),
+    __builtin_bit_cast(uint32_t, 0.4166667f),  __builtin_bit_cast(uint32_t, 0.583333f),
+    __builtin_bit_cast(uint32_t, 0.8333333f)};
+constexpr uint32_t kLutFirst = kThresholdBits[0] >> 20;                      // 0x3B2
+constexpr uint32_t kLutLast = __builtin_bit_cast(uint32_t, 1.0f) >> 20;      // 0x3F8
+constexpr int kLutSize = int(kLutLast - kLutFirst) + 1;                      // 71
+constexpr float kLutFloor = __builtin_bit_cast(float, kLutFirst << 20);      // 2^-9 * 1.25
+
+struct RankLut {
+    uint32_t e[kLutSize];
+};
+constexpr RankLut make_rank_lut() {
+    RankLut lut{};
+    for (int i = 0; i < kLutSize; ++i) {
+        const uint32_t bucket = kLutFirst + uint32_t(i);
+        uint32_t below = 0, thr = 0xFFFFFu;
+        for (int j = 0; j < 7; ++j) {
+            if ((kThresholdBits[j] >> 20) < bucket) ++below;
+            if ((kThresholdBits[j] >> 20) == bucket) thr = kThresholdBits[j] & 0xFFFFFu;
+        }
+        lut.e[i] = ((7u - below) << 28) | thr;
+    }
+    return lut;
+}
+constexpr bool thresholds_in_distinct_buckets() {
+    for (int j = 1; j < 7; ++j)
+        if ((kThresholdBits[j] >> 20) <= (kThresholdBits[j - 1] >> 20)) return false;
+    return (kThresholdBits[6] >> 20) < kLutLast;
+}
+static_assert(thresholds_in_distinct_buckets(), "the bucket table needs at most one threshold per bucket");
+__device__ const RankLut kRankLut = make_rank_lut();
+
+// 8 scaled values -> one packed dword (byte j = element 2j in the high nibble, 2j+1 in the low nibble).  `lut` is indexed
+// by the absolute bucket number.  GUARD is the rare path for a block whose absmax or 1/absmax is not finite (subnormal,
+// inf or NaN weights): NaN products (0*inf, inf*0, NaN) must rank as 0 with no sign, which is what the reference's float
+// compares do with a NaN, and inf must rank as 7.
+template <bool GUARD>
+__device__ __forceinline__ uint32_t encode8(const float (&v)[8], float inv, const uint32_t *lut) {
+    constexpr int order[8] = {6, 7, 4, 5, 2, 3, 0, 1};  // the first nibble pushed ends up in bits 31..28
+    uint32_t word = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        float x = v[order[k]] * inv;
+        if (GUARD) x = (x != x) ? 0.0f : x;
+        x = x + 0.0f;  // -0.0 (a -0.0 weight or an underflowed product) -> +0.0: `x < 0` is false for it
+        float mag = __builtin_fmaxf(__builtin_fabsf(x), kLutFloor);
+        if (GUARD) mag = __builtin_fminf(mag, 1.0f);
+        const uint32_t mb = __builtin_bit_cast(uint32_t, mag);
+        const uint32_t entry = lut[mb >> 20];
+        const uint32_t r = entry - (mb & 0xFFFFFu);  // bits 30..28 = 7 - rank
+        // bit 31 from x, the rest from r: (r & ~C) | (x & C)
+        const uint32_t nib = __builtin_amdgcn_bitop3_b32(r, __builtin_bit_cast(uint32_t, x), 0x80000000u, 0xD8);
+        word = __builtin_amdgcn_alignbit(word, nib, 28);  // (word << 4) | (nib >> 28)
+    }
+    // r -> code in all eight nibbles at once: flip r1 and r0, code bit 2 = r2 ^ r1
+    return (word ^ 0x33333333u) ^ ((word << 1) & 0x44444444u);
 }
 
+// The 8 elements starting at e0 as f32 (zeros past n).
 template <int DT>
 __device__ __forceinline__ void load8(const void *w, int64_t e0, int64_t n, float (&v)[8]) {
     if (e0 + 8 <= n) {
@@ -58,37 +122,62 @@ __device__ __forceinline__ void load8(const void *w, int64_t e0, int64_t n, floa
     }
 }
 
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_umax(uint32_t v) {
+    const uint32_t moved = uint32_t(__builtin_amdgcn_update_dpp(0, int(v), CTRL, 0xF, 0xF, false));
+    return v > moved ? v : moved;
+}
+
 template <int DT>
 __global__ __launch_bounds__(kQThreads) void quantize_kernel(const void *__restrict__ w, uint8_t *__restrict__ packed,
                                                              float *__restrict__ absmax, int64_t n, int bs_shift) {
-    __shared__ float s_wave_max[kQThreads / 64];
+    __shared__ uint32_t s_wave_max[kQThreads / 64];
+    __shared__ uint32_t s_lut[kLutLast + 1];  // indexed by bucket; only the top kLutSize entries are ever read
     const int tid = threadIdx.x;
     const int64_t e0 = (int64_t(blockIdx.x) * kQThreads + tid) * 8;
+    // The table entry is loaded first and unconditionally: vector-memory results return in issue order, and a load under
+    // a divergent branch would be drained on its own, so this way its (L2) latency hides under the weight load's.
+    const uint32_t lut_entry = kRankLut.e[tid < kLutSize ? tid : kLutSize - 1];
     float v[8];
-    load8<DT>(w, e0, n, v);
+    if ((int64_t(blockIdx.x) + 1) * (kQThreads * 8) <= n)  // uniform: every workgroup but the last
+        load8<DT>(w, e0, e0 + 8, v);
+    else
+        load8<DT>(w, e0, n, v);
+    if (tid < kLutSize) s_lut[kLutFirst + tid] = lut_entry;
 
-    float m = 0.0f;
+    // Block maximum on the BIT PATTERNS of |w| (same order as the values; a NaN weight, whose pattern is above inf,
+    // propagates into absmax the way numpy's max does).  lanes_per_block is uniform across the grid, so these are scalar
+    // branches; up to 16 lanes the butterfly is pure DPP.
+    uint32_t mb = 0;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) m = __builtin_fmaxf(m, __builtin_fabsf(v[i]));
+    for (int i = 0; i < 8; ++i) mb = max(mb, __builtin_bit_cast(uint32_t, v[i]) & 0x7FFFFFFFu);
     const int lanes_per_block = 1 << (bs_shift - 3);
-    for (int mask = 1; mask < lanes_per_block && mask < 64; mask <<= 1) m = __builtin_fmaxf(m, __shfl_xor(m, mask));
-    if (lanes_per_block > 64) {  // uniform across the grid
-        if ((tid & 63) == 0) s_wave_max[tid >> 6] = m;
-        __syncthreads();
+    mb = dpp_umax<0xB1>(mb);                                                        // quad_perm [1,0,3,2]
+    mb = dpp_umax<0x4E>(mb);                                                        // quad_perm [2,3,0,1]
+    if (lanes_per_block >= 8) mb = dpp_umax<0x141>(mb);                             // row_half_mirror
+    if (lanes_per_block >= 16) mb = dpp_umax<0x140>(mb);                            // row_mirror
+    if (lanes_per_block >= 32) mb = max(mb, uint32_t(__shfl_xor(int(mb), 16)));
+    if (lanes_per_block >= 64) mb = max(mb, uint32_t(__shfl_xor(int(mb), 32)));
+    if (lanes_per_block > 64 && (tid & 63) == 0) s_wave_max[tid >> 6] = mb;
+    __syncthreads();  // s_lut (and s_wave_max) visible
+    if (lanes_per_block > 64) {
         const int waves_per_block = lanes_per_block >> 6;
         const int first = ((tid >> 6) / waves_per_block) * waves_per_block;
-        for (int i = 0; i < waves_per_block; ++i) m = __builtin_fmaxf(m, s_wave_max[first + i]);
+        for (int i = 0; i < waves_per_block; ++i) mb = max(mb, s_wave_max[first + i]);
     }
     if (e0 >= n) return;
+    const float m = __builtin_bit_cast(float, mb);
     if ((tid & (lanes_per_block - 1)) == 0) absmax[e0 >> bs_shift] = m;
 
-    const float inv = 1.0f / m;
-    uint32_t word = 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const uint32_t q = quantize_one(v[i] * inv);
-        word |= q << (8 * (i >> 1) + ((i & 1) ? 0 : 4));
-    }
+    // x = w * (1/absmax) as the reference computes it.  An all-zero block (1/0 = inf, 0*inf = NaN, every compare false)
+    // encodes as all +0, which scaling by 0 reproduces without the NaN.
+    const float inv = m > 0.0f ? 1.0f / m : 0.0f;
+    const bool not_finite = !(inv <= 3.4028234664e38f && m <= 3.4028234664e38f);  // inf, NaN or subnormal absmax
+    uint32_t word;
+    if (__builtin_amdgcn_ballot_w64(not_finite) != 0)  // wave-uniform: keeps the guard out of the hot path
+        word = encode8<true>(v, inv, s_lut);
+    else
+        word = encode8<false>(v, inv, s_lut);
     if (e0 + 8 <= n) {
         reinterpret_cast<uint32_t *>(packed)[e0 / 8] = word;
     } else {
