@@ -122,7 +122,8 @@ FP4_HIP_API int fp4_hip_quantize_blockwise(const void *w, int w_dtype, uint8_t *
 
 /*
  * Tuning hook for benchmarks/sweeps: selects a kernel geometry by name
- * ("dequant", "gemv").  variant < 0 restores the built-in heuristic.
+ * ("dequant", "gemv", "gemm_small", "quantize" = workgroups per CU of the persistent
+ * grid).  variant < 0 (quantize: 0) restores the built-in heuristic.
  * Process-wide; not part of the reference surface.
  */
 FP4_HIP_API int fp4_hip_set_variant(const char *kernel, int variant);

@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #define CK(x)                                                                             \
@@ -98,7 +99,8 @@ __global__ __launch_bounds__(THREADS) void quant(const u32x4 *__restrict__ w, ui
 
 // ---- variant 2: bit-plane ranking (7 subtracts + 5 v_bitop3 + 4 v_alignbit per element), optional persistent loop with a
 // one-tile prefetch so one wave's arithmetic overlaps the next tile's HBM latency
-enum : int { P_PLANES = 1, P_PERSIST = 2, P_NT = 4, P_NOLOAD = 8, P_NOSTORE = 16 };
+enum : int { P_PLANES = 1, P_PERSIST = 2, P_NT = 4, P_NOLOAD = 8, P_NOSTORE = 16, P_LUT = 32 };
+__device__ uint32_t g_lut[71];  // filled by the host: (7 - rank_lo) << 28 | threshold_low20 for buckets 0x3B2..0x3F8
 __device__ __forceinline__ uint32_t push(uint32_t acc, uint32_t plane) { return __builtin_amdgcn_alignbit(acc, plane, 31); }
 
 __device__ __forceinline__ uint32_t nibble_planes(uint32_t acc, uint32_t sign_src, float a_f) {
@@ -117,7 +119,7 @@ __device__ __forceinline__ uint32_t nibble_planes(uint32_t acc, uint32_t sign_sr
 }
 
 template <int FLAGS>
-__device__ __forceinline__ void quant_tile(const u32x4 raw, int64_t g, int tid, uint32_t *__restrict__ packed, float *__restrict__ absmax) {
+__device__ __forceinline__ void quant_tile(const u32x4 raw, int64_t g, int tid, uint32_t *__restrict__ packed, float *__restrict__ absmax, const uint32_t *lut) {
     uint32_t sgn[8];
     float av[8];
 #pragma unroll
@@ -137,7 +139,20 @@ __device__ __forceinline__ void quant_tile(const u32x4 raw, int64_t g, int tid, 
         if ((tid & 7) == 0) absmax[g >> 3] = m;
     const float inv = m > 0.0f ? 1.0f / m : 0.0f;
     uint32_t word = 0;
-    if (FLAGS & P_PLANES) {
+    if (FLAGS & P_LUT) {
+        constexpr int order[8] = {6, 7, 4, 5, 2, 3, 0, 1};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float x = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, av[order[k]]) | (sgn[order[k]] & 0x80000000u)) * inv;
+            x = x + 0.0f;
+            const float mag = __builtin_fmaxf(__builtin_fabsf(x), __builtin_bit_cast(float, 0x3B200000u));
+            const uint32_t mb = __builtin_bit_cast(uint32_t, mag);
+            const uint32_t r = lut[mb >> 20] - (mb & 0xFFFFFu);
+            const uint32_t nib = __builtin_amdgcn_bitop3_b32(r, __builtin_bit_cast(uint32_t, x), 0x80000000u, 0xD8);
+            word = __builtin_amdgcn_alignbit(word, nib, 28);
+        }
+        word = (word ^ 0x33333333u) ^ ((word << 1) & 0x44444444u);
+    } else if (FLAGS & P_PLANES) {
         constexpr int order[8] = {6, 7, 4, 5, 2, 3, 0, 1};
 #pragma unroll
         for (int k = 0; k < 8; ++k) word = nibble_planes(word, sgn[order[k]], av[order[k]] * inv);
@@ -159,6 +174,12 @@ __device__ __forceinline__ void quant_tile(const u32x4 raw, int64_t g, int tid, 
 template <int THREADS, int FLAGS>
 __global__ __launch_bounds__(THREADS) void quant2(const u32x4 *__restrict__ w, uint32_t *__restrict__ packed, float *__restrict__ absmax, int ntiles) {
     const int tid = threadIdx.x;
+    __shared__ uint32_t s_lut[0x3F9];
+    if (FLAGS & P_LUT) {
+        const uint32_t e = g_lut[tid < 71 ? tid : 70];
+        if (tid < 71) s_lut[0x3B2 + tid] = e;
+        __syncthreads();
+    }
     if (FLAGS & P_PERSIST) {
         int t = blockIdx.x;
         u32x4 cur = (FLAGS & P_NT) ? __builtin_nontemporal_load(w + int64_t(t) * THREADS + tid) : w[int64_t(t) * THREADS + tid];
@@ -166,7 +187,7 @@ __global__ __launch_bounds__(THREADS) void quant2(const u32x4 *__restrict__ w, u
             const int tn = t + gridDim.x;
             const int tl = tn < ntiles ? tn : t;  // clamped: the load stays unconditional
             const u32x4 nxt = (FLAGS & P_NT) ? __builtin_nontemporal_load(w + int64_t(tl) * THREADS + tid) : w[int64_t(tl) * THREADS + tid];
-            quant_tile<FLAGS>(cur, int64_t(t) * THREADS + tid, tid, packed, absmax);
+            quant_tile<FLAGS>(cur, int64_t(t) * THREADS + tid, tid, packed, absmax, s_lut);
             if (tn >= ntiles) break;
             cur = nxt;
             t = tn;
@@ -180,7 +201,7 @@ __global__ __launch_bounds__(THREADS) void quant2(const u32x4 *__restrict__ w, u
         } else {
             raw = (FLAGS & P_NT) ? __builtin_nontemporal_load(w + g) : w[g];
         }
-        quant_tile<FLAGS>(raw, g, tid, packed, absmax);
+        quant_tile<FLAGS>(raw, g, tid, packed, absmax, s_lut);
     }
 }
 
@@ -193,6 +214,21 @@ int main() {
         CK(hipMalloc(&p[i], n / 2));
         CK(hipMalloc(&a[i], n / 64 * 4));
         CK(hipMemset(w[i], 0x3c + i, n * 2));
+    }
+    {
+        const float tf[7] = {0.00260417f, 0.0859375f, 0.20833333f, 0.29166667f, 0.4166667f, 0.583333f, 0.8333333f};
+        uint32_t tb[7], lut[71];
+        for (int j = 0; j < 7; ++j) memcpy(&tb[j], &tf[j], 4);
+        for (int i = 0; i < 71; ++i) {
+            const uint32_t bucket = 0x3B2 + i;
+            uint32_t below = 0, thr = 0xFFFFF;
+            for (int j = 0; j < 7; ++j) {
+                if ((tb[j] >> 20) < bucket) ++below;
+                if ((tb[j] >> 20) == bucket) thr = tb[j] & 0xFFFFF;
+            }
+            lut[i] = ((7 - below) << 28) | thr;
+        }
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(g_lut), lut, sizeof(lut)));
     }
     hipStream_t s;
     CK(hipStreamCreate(&s));
@@ -231,6 +267,7 @@ int main() {
         hipLaunchKernelGGL((quant<T, I, (F)>), dim3(unsigned(n / 8 / (T * I))), dim3(T), 0, s, (const u32x4 *)w[i], (uint32_t *)p[i], \
                            (float *)a[i]);                                                                                      \
     })
+    if (getenv("EXP_QUANT_ALL")) {
     RUN(512, 1, F_FLOATCMP);
     RUN(512, 1, 0);
     RUN(512, 1, F_DPP);
@@ -250,12 +287,29 @@ int main() {
     RUN(256, 4, F_DPP | F_NTLOAD | F_NOQUANT);
     RUN(256, 4, F_DPP | F_NTLOAD | F_NOQUANT | F_NOABSMAX);
     RUN(1024, 1, F_DPP);
+    }
 #define RUN2(T, F, GRID)                                                                                                        \
     run("v2 threads=" #T " flags=" #F " grid=" #GRID, [&](int i) {                                                                \
         const int ntiles = int(n / 8 / T);                                                                                        \
         const int grid = (GRID) > 0 ? (GRID) : ntiles;                                                                            \
         hipLaunchKernelGGL((quant2<T, (F)>), dim3(grid), dim3(T), 0, s, (const u32x4 *)w[i], (uint32_t *)p[i], (float *)a[i], ntiles); \
     })
+    if (!getenv("EXP_QUANT_ALL")) {
+        RUN2(512, P_LUT, 0);
+        RUN2(256, P_LUT, 0);
+        RUN2(256, P_LUT | P_NT, 0);
+        RUN2(256, P_LUT | P_NOLOAD | P_NOSTORE, 0);
+        RUN2(256, P_LUT | P_PERSIST, 256 * 8);
+        RUN2(256, P_LUT | P_PERSIST, 256 * 6);
+        RUN2(256, P_LUT | P_PERSIST, 256 * 4);
+        RUN2(512, P_LUT | P_PERSIST, 256 * 4);
+        RUN2(512, P_LUT | P_PERSIST, 256 * 3);
+        RUN2(512, P_LUT | P_PERSIST, 256 * 2);
+        RUN2(1024, P_LUT | P_PERSIST, 256 * 2);
+        RUN2(256, P_LUT | P_PERSIST | P_NT, 256 * 8);
+        RUN2(128, P_LUT, 0);
+        return 0;
+    }
     RUN2(256, P_PLANES | P_NOLOAD, 0);
     RUN2(256, P_PLANES | P_NOLOAD | P_NOSTORE, 0);
     RUN2(256, P_PLANES | P_NOSTORE, 0);

@@ -89,6 +89,10 @@ if what in ("quant", "all"):
         RW = 16
         ws = [torch.randn(n, device=dev).to(dt) for _ in range(RW)]
         nbytes = n * isz + n // 2 + 4 * (n // 64)
-        cold = capture(lambda: [hipabi.quantize(ws[i % RW], 64) for i in range(RW * 2)])
-        c, cm = timeit(cold, RW * 2)
-        print(f"quantize {name} {M}x{K} bs64 cold {c:7.2f} us (min {cm:7.2f}) = {nbytes / c / 1e3:7.0f} GB/s", flush=True)
+        for wg in ([0] if "--grids" not in sys.argv else [0, 1, 2, 3, 4, 6, 8, 16, 1 << 20]):
+            hipabi.set_variant("quantize", wg)
+            cold = capture(lambda: [hipabi.quantize(ws[i % RW], 64) for i in range(RW * 2)])
+            c, cm = timeit(cold, RW * 2)
+            tag = "" if wg == 0 else f" wg/cu={wg}"
+            print(f"quantize {name} {M}x{K} bs64{tag} cold {c:7.2f} us (min {cm:7.2f}) = {nbytes / c / 1e3:7.0f} GB/s", flush=True)
+        hipabi.set_variant("quantize", 0)

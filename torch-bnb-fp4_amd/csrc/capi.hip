@@ -14,6 +14,7 @@ thread_local char g_last_error[512] = "";
 void set_dequant_variant(int v);
 void set_gemv_variant(int v);
 void set_small_variant(int v);
+void set_quantize_variant(int v);
 
 void set_error(const char *fmt, ...) {
     va_list ap;
@@ -29,6 +30,19 @@ int check_launch(const char *what) {
     if (err == hipSuccess) return FP4_OK;
     set_error("%s: kernel launch failed: %s", what, hipGetErrorString(err));
     return FP4_ERR_LAUNCH;
+}
+
+// Compute units of the current device (256 on MI355X), cached per device ordinal; used to size persistent grids.
+int device_cu_count() {
+    static int cached[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (cached[dev] == 0) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        cached[dev] = cus;
+    }
+    return cached[dev];
 }
 
 }  // namespace fp4
@@ -54,6 +68,10 @@ extern "C" int fp4_hip_set_variant(const char *kernel, int variant) {
     }
     if (kernel && !std::strcmp(kernel, "gemv")) {
         fp4::set_gemv_variant(variant);
+        return FP4_OK;
+    }
+    if (kernel && !std::strcmp(kernel, "quantize")) {
+        fp4::set_quantize_variant(variant);
         return FP4_OK;
     }
     if (kernel && !std::strcmp(kernel, "gemm_small")) {

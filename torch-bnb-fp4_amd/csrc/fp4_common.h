@@ -52,6 +52,7 @@ static_assert(kMagBits[0][2] == kMagBits[1][2] && kMagBits[0][3] == kMagBits[1][
 // ---- status plumbing ---------------------------------------------------------------
 void set_error(const char *fmt, ...);
 int check_launch(const char *what);
+int device_cu_count();
 
 inline int ilog2_exact(int64_t v) {  // log2(v) if v is a power of two, else -1
     if (v <= 0 || (v & (v - 1))) return -1;

@@ -10,6 +10,8 @@
 // critical path (see encode8).  Each lane owns 8 consecutive elements (one 16-byte load for 16-bit inputs) and emits
 // one packed dword, so loads and stores are both fully coalesced; the block maximum is a butterfly over
 // the bs/8 lanes that share a block (DPP up to 16 lanes, cross-wave through LDS only for blocksize > 512).
+#include <algorithm>
+
 #include "fp4_common.h"
 
 namespace fp4 {
@@ -91,34 +93,53 @@ __device__ __forceinline__ uint32_t encode8(const float (&v)[8], float inv, cons
     return (word ^ 0x33333333u) ^ ((word << 1) & 0x44444444u);
 }
 
-// The 8 elements starting at e0 as f32 (zeros past n).
+// One lane's 8 elements of a full tile, still in their storage type (16 or 32 bytes), streamed past the caches.
 template <int DT>
-__device__ __forceinline__ void load8(const void *w, int64_t e0, int64_t n, float (&v)[8]) {
-    if (e0 + 8 <= n) {
-        if constexpr (DT == FP4_DTYPE_F32) {
-            const f32x4 a = reinterpret_cast<const f32x4 *>(w)[e0 / 4];
-            const f32x4 b = reinterpret_cast<const f32x4 *>(w)[e0 / 4 + 1];
-            v[0] = a.x, v[1] = a.y, v[2] = a.z, v[3] = a.w, v[4] = b.x, v[5] = b.y, v[6] = b.z, v[7] = b.w;
-        } else {
-            const u32x4 a = reinterpret_cast<const u32x4 *>(w)[e0 / 8];
+struct RawTile {
+    uint32_t d[DT == FP4_DTYPE_F32 ? 8 : 4];
+};
+
+template <int DT>
+__device__ __forceinline__ RawTile<DT> load_raw(const void *w, int64_t e0) {
+    RawTile<DT> r;
+    if constexpr (DT == FP4_DTYPE_F32) {
+        const u32x4 lo = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(w) + e0 / 4);
+        const u32x4 hi = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(w) + e0 / 4 + 1);
+        r.d[0] = lo.x, r.d[1] = lo.y, r.d[2] = lo.z, r.d[3] = lo.w, r.d[4] = hi.x, r.d[5] = hi.y, r.d[6] = hi.z, r.d[7] = hi.w;
+    } else {
+        const u32x4 lo = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(w) + e0 / 8);
+        r.d[0] = lo.x, r.d[1] = lo.y, r.d[2] = lo.z, r.d[3] = lo.w;
+    }
+    return r;
+}
+
+template <int DT>
+__device__ __forceinline__ void unpack8(const RawTile<DT> &r, float (&v)[8]) {
+    if constexpr (DT == FP4_DTYPE_F32) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                v[2 * i] = to_f32<DT>(uint16_t(a[i] & 0xFFFFu));
-                v[2 * i + 1] = to_f32<DT>(uint16_t(a[i] >> 16));
-            }
-        }
+        for (int i = 0; i < 8; ++i) v[i] = __builtin_bit_cast(float, r.d[i]);
     } else {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            float t = 0.0f;
-            if (e0 + i < n) {
-                if constexpr (DT == FP4_DTYPE_F32)
-                    t = reinterpret_cast<const float *>(w)[e0 + i];
-                else
-                    t = to_f32<DT>(reinterpret_cast<const uint16_t *>(w)[e0 + i]);
-            }
-            v[i] = t;
+        for (int i = 0; i < 4; ++i) {
+            v[2 * i] = to_f32<DT>(uint16_t(r.d[i] & 0xFFFFu));
+            v[2 * i + 1] = to_f32<DT>(uint16_t(r.d[i] >> 16));
         }
+    }
+}
+
+// The ragged last tile: element by element, zeros past n.
+template <int DT>
+__device__ __forceinline__ void load8_tail(const void *w, int64_t e0, int64_t n, float (&v)[8]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        float t = 0.0f;
+        if (e0 + i < n) {
+            if constexpr (DT == FP4_DTYPE_F32)
+                t = reinterpret_cast<const float *>(w)[e0 + i];
+            else
+                t = to_f32<DT>(reinterpret_cast<const uint16_t *>(w)[e0 + i]);
+        }
+        v[i] = t;
     }
 }
 
@@ -128,46 +149,38 @@ __device__ __forceinline__ uint32_t dpp_umax(uint32_t v) {
     return v > moved ? v : moved;
 }
 
-template <int DT>
-__global__ __launch_bounds__(kQThreads) void quantize_kernel(const void *__restrict__ w, uint8_t *__restrict__ packed,
-                                                             float *__restrict__ absmax, int64_t n, int bs_shift) {
-    __shared__ uint32_t s_wave_max[kQThreads / 64];
-    __shared__ uint32_t s_lut[kLutLast + 1];  // indexed by bucket; only the top kLutSize entries are ever read
-    const int tid = threadIdx.x;
-    const int64_t e0 = (int64_t(blockIdx.x) * kQThreads + tid) * 8;
-    // The table entry is loaded first and unconditionally: vector-memory results return in issue order, and a load under
-    // a divergent branch would be drained on its own, so this way its (L2) latency hides under the weight load's.
-    const uint32_t lut_entry = kRankLut.e[tid < kLutSize ? tid : kLutSize - 1];
-    float v[8];
-    if ((int64_t(blockIdx.x) + 1) * (kQThreads * 8) <= n)  // uniform: every workgroup but the last
-        load8<DT>(w, e0, e0 + 8, v);
-    else
-        load8<DT>(w, e0, n, v);
-    if (tid < kLutSize) s_lut[kLutFirst + tid] = lut_entry;
-
+// One tile of kQThreads * 8 elements: block maxima, scales, codes.  TAIL = the ragged last tile (lanes past n idle, partial
+// dword stores); full tiles have no divergent memory operation at all, so the compiler can count what is in flight.
+template <bool TAIL>
+__device__ __forceinline__ void quantize_tile(const float (&v)[8], int64_t e0, int64_t n, int tid, int bs_shift,
+                                              uint8_t *__restrict__ packed, float *__restrict__ absmax,
+                                              const uint32_t *lut, uint32_t *s_wave_max) {
     // Block maximum on the BIT PATTERNS of |w| (same order as the values; a NaN weight, whose pattern is above inf,
     // propagates into absmax the way numpy's max does).  lanes_per_block is uniform across the grid, so these are scalar
     // branches; up to 16 lanes the butterfly is pure DPP.
+    const int lanes_per_block = 1 << (bs_shift - 3);
     uint32_t mb = 0;
 #pragma unroll
     for (int i = 0; i < 8; ++i) mb = max(mb, __builtin_bit_cast(uint32_t, v[i]) & 0x7FFFFFFFu);
-    const int lanes_per_block = 1 << (bs_shift - 3);
     mb = dpp_umax<0xB1>(mb);                                                        // quad_perm [1,0,3,2]
     mb = dpp_umax<0x4E>(mb);                                                        // quad_perm [2,3,0,1]
     if (lanes_per_block >= 8) mb = dpp_umax<0x141>(mb);                             // row_half_mirror
     if (lanes_per_block >= 16) mb = dpp_umax<0x140>(mb);                            // row_mirror
     if (lanes_per_block >= 32) mb = max(mb, uint32_t(__shfl_xor(int(mb), 16)));
     if (lanes_per_block >= 64) mb = max(mb, uint32_t(__shfl_xor(int(mb), 32)));
-    if (lanes_per_block > 64 && (tid & 63) == 0) s_wave_max[tid >> 6] = mb;
-    __syncthreads();  // s_lut (and s_wave_max) visible
     if (lanes_per_block > 64) {
+        if ((tid & 63) == 0) s_wave_max[tid >> 6] = mb;
+        __syncthreads();
         const int waves_per_block = lanes_per_block >> 6;
         const int first = ((tid >> 6) / waves_per_block) * waves_per_block;
         for (int i = 0; i < waves_per_block; ++i) mb = max(mb, s_wave_max[first + i]);
+        __syncthreads();  // s_wave_max is rewritten by the next tile
     }
-    if (e0 >= n) return;
+    if (TAIL && e0 >= n) return;
     const float m = __builtin_bit_cast(float, mb);
-    if ((tid & (lanes_per_block - 1)) == 0) absmax[e0 >> bs_shift] = m;
+    // every lane of a block holds the same maximum; in a full tile all of them store it (same address, same value) so that
+    // the store is not under a divergent branch
+    if (!TAIL || (tid & (lanes_per_block - 1)) == 0) __builtin_nontemporal_store(m, absmax + (e0 >> bs_shift));
 
     // x = w * (1/absmax) as the reference computes it.  An all-zero block (1/0 = inf, 0*inf = NaN, every compare false)
     // encodes as all +0, which scaling by 0 reproduces without the NaN.
@@ -175,18 +188,64 @@ __global__ __launch_bounds__(kQThreads) void quantize_kernel(const void *__restr
     const bool not_finite = !(inv <= 3.4028234664e38f && m <= 3.4028234664e38f);  // inf, NaN or subnormal absmax
     uint32_t word;
     if (__builtin_amdgcn_ballot_w64(not_finite) != 0)  // wave-uniform: keeps the guard out of the hot path
-        word = encode8<true>(v, inv, s_lut);
+        word = encode8<true>(v, inv, lut);
     else
-        word = encode8<false>(v, inv, s_lut);
-    if (e0 + 8 <= n) {
-        reinterpret_cast<uint32_t *>(packed)[e0 / 8] = word;
+        word = encode8<false>(v, inv, lut);
+    if (!TAIL || e0 + 8 <= n) {
+        __builtin_nontemporal_store(word, reinterpret_cast<uint32_t *>(packed) + e0 / 8);
     } else {
         const int nbytes = int((n - e0 + 1) / 2);
         for (int b = 0; b < nbytes; ++b) packed[e0 / 2 + b] = uint8_t(word >> (8 * b));
     }
 }
 
+// Persistent: a workgroup walks the full tiles with stride gridDim.x and keeps the NEXT tile's load in flight while it
+// ranks the current one, so the VALU work of one tile overlaps the HBM latency of the next (a one-shot grid leaves the
+// first and last generation of waves un-overlapped).  The ragged last tile, if any, is done after the loop by the
+// workgroup whose turn it would have been.  Every condition on a tile index is uniform across the workgroup.
+template <int DT>
+__global__ __launch_bounds__(kQThreads) void quantize_kernel(const void *__restrict__ w, uint8_t *__restrict__ packed,
+                                                             float *__restrict__ absmax, int64_t n, int bs_shift) {
+    __shared__ uint32_t s_wave_max[kQThreads / 64];
+    __shared__ uint32_t s_lut[kLutLast + 1];  // indexed by bucket; only the top kLutSize entries are ever read
+    constexpr int64_t kTile = int64_t(kQThreads) * 8;
+    const int tid = threadIdx.x;
+    const int64_t nfull = n / kTile;
+
+    // The table entry is loaded first and unconditionally: vector-memory results return in issue order, and a load under
+    // a divergent branch would be drained on its own, so this way its (L2) latency hides under the first weight load's.
+    const uint32_t lut_entry = kRankLut.e[tid < kLutSize ? tid : kLutSize - 1];
+    int64_t tile = blockIdx.x;
+    RawTile<DT> cur{};
+    if (tile < nfull) cur = load_raw<DT>(w, tile * kTile + tid * 8);
+    if (tid < kLutSize) s_lut[kLutFirst + tid] = lut_entry;
+    __syncthreads();
+
+    float v[8];
+    while (tile < nfull) {
+        const int64_t next = tile + gridDim.x;
+        RawTile<DT> nxt{};
+        if (next < nfull) nxt = load_raw<DT>(w, next * kTile + tid * 8);
+        unpack8<DT>(cur, v);
+        quantize_tile<false>(v, tile * kTile + tid * 8, n, tid, bs_shift, packed, absmax, s_lut, s_wave_max);
+        cur = nxt;
+        tile = next;
+    }
+    if (tile == nfull && nfull * kTile < n) {  // exactly one workgroup gets here with the ragged tile
+        const int64_t e0 = tile * kTile + tid * 8;
+        load8_tail<DT>(w, e0, n, v);
+        quantize_tile<true>(v, e0, n, tid, bs_shift, packed, absmax, s_lut, s_wave_max);
+    }
+}
+
 }  // namespace
+}  // namespace fp4
+
+namespace fp4 {
+namespace {
+int g_quant_wg_per_cu = 0;  // 0 = default; experiments: fp4_hip_set_variant("quantize", workgroups per CU)
+}
+void set_quantize_variant(int v) { g_quant_wg_per_cu = v > 0 ? v : 0; }
 }  // namespace fp4
 
 extern "C" int fp4_hip_quantize_blockwise(const void *w, int w_dtype, uint8_t *packed, float *absmax, int64_t n,
@@ -211,7 +270,10 @@ extern "C" int fp4_hip_quantize_blockwise(const void *w, int w_dtype, uint8_t *p
         return FP4_ERR_UNSUPPORTED;
     }
     const int64_t per_wg = int64_t(kQThreads) * 8;
-    const unsigned blocks = (unsigned)((n + per_wg - 1) / per_wg);
+    const int64_t ntiles = (n + per_wg - 1) / per_wg;
+    // 4 workgroups of 512 threads fill a CU's 2048 wave slots; each keeps one tile in flight while it ranks another
+    const int wg_per_cu = g_quant_wg_per_cu ? g_quant_wg_per_cu : 4;
+    const unsigned blocks = (unsigned)std::min<int64_t>(ntiles, int64_t(device_cu_count()) * wg_per_cu);  // ntiles >= 1
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch (w_dtype) {
         case FP4_DTYPE_F16:
