@@ -84,6 +84,26 @@ if what in ("gemv", "all"):
     c, cm = timeit(cold, R * 2)
     print(f"gemv f32 {M}x{K} cold {c:6.2f} us = {(n // 2 + 4 * (n // 64) + (K + M) * 4) / c / 1e3:6.0f} GB/s", flush=True)
 
+if what == "regx":
+    # register-x GEMV geometries at one shape: iters x {auto K split, 8-way split over 8 waves}; variant word = 1<<24 | ks<<8 | iters
+    for dt, name, isz in ((torch.bfloat16, "bf16", 2),):
+        x = torch.randn(K, device=dev).to(dt)
+        nbytes = n // 2 + 4 * (n // 64) + (K + M) * isz
+        res = []
+        for ks in (0, 8):
+            for it in (1, 2, 4, 8):
+                hipabi.set_variant("gemv", (1 << 24) | (ks << 8) | it)
+                try:
+                    cold = capture(lambda: [hipabi.gemv(x, packed[i % R], absmax[i % R], M, K, 64) for i in range(R * 2)])
+                except AssertionError as e:
+                    continue
+                c, cm = timeit(cold, R * 2)
+                print(f"gemv regx {name} {M}x{K} ks={ks} iters={it} cold {c:6.2f} us (min {cm:6.2f}) = {nbytes / c / 1e3:6.0f} GB/s", flush=True)
+        hipabi.set_variant("gemv", -1)
+        cold = capture(lambda: [hipabi.gemv(x, packed[i % R], absmax[i % R], M, K, 64) for i in range(R * 2)])
+        c, cm = timeit(cold, R * 2)
+        print(f"gemv default {name} {M}x{K} cold {c:6.2f} us (min {cm:6.2f}) = {nbytes / c / 1e3:6.0f} GB/s", flush=True)
+
 if what in ("quant", "all"):
     for dt, name, isz in ((torch.bfloat16, "bf16", 2), (torch.float16, "f16", 2), (torch.float32, "f32", 4)):
         RW = 16

@@ -246,8 +246,10 @@ __global__ __launch_bounds__(WAVES * 64) void gemv16_kernel(const uint16_t *__re
 //   * a workgroup handles ITERS row-pairs per row group; every weight load of the workgroup is issued
 //     before the first dot2; per (row, band) partial sums meet in LDS (KSPLIT floats per row), one
 //     barrier at the very end; with KSPLIT == 1 nothing is shared at all.
+// (a deep x slice, G = 4, is held to 128 VGPRs = 4 waves per SIMD: at 142 only three 4-wave workgroups fit a CU, the
+// 1024 workgroups of a 4096-row layer no longer run as one resident round and a third of the chip idles in the second)
 template <int DT, int KSPLIT, int G, int ITERS, int WAVES = 4>
-__global__ __launch_bounds__(WAVES * 64) void gemv16_regx_kernel(const uint16_t *__restrict__ x, const uint8_t *__restrict__ W,
+__global__ __launch_bounds__(WAVES * 64, (G >= 4 ? 4 : 1)) void gemv16_regx_kernel(const uint16_t *__restrict__ x, const uint8_t *__restrict__ W,
                                                           const float *__restrict__ absmax,
                                                           const uint16_t *__restrict__ bias, uint16_t *__restrict__ out,
                                                           int M, int K, int bs_shift, int out_f32) {
@@ -273,35 +275,62 @@ __global__ __launch_bounds__(WAVES * 64) void gemv16_regx_kernel(const uint16_t 
         cidx[g] = live[g] ? c : C - 1;
     }
     // 1. this lane's slice of x first: results return in issue order, and x (L2-resident, shared by every
-    //    workgroup) must not queue behind the HBM weight stream
+    //    workgroup) must not queue behind the HBM weight stream.  With a deep slice (G > 1: long rows) the x loads
+    //    alone keep the texture path busy for over a microsecond, so there the issue order is group-major - x of
+    //    group g, then every row's weights of group g - and the HBM stream starts after a quarter of x.
+    constexpr bool GMAJOR = G > 1;
     u32x4 xraw[G][4];
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) xraw[g][q] = reinterpret_cast<const u32x4 *>(x)[cidx[g] * 4 + q];
-    }
-    // 2. the whole weight stream of this lane, issued up front
     u32x4 wq[ITERS][G];
     float am[ITERS][G];
-    int rowi[ITERS];
+    int rowi[ITERS], rclamp[ITERS];
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
         const int local = 2 * (it * RG + rw) + half;
         const int row = row_base + local;
         rowi[it] = local;
-        const int rclamp = row < M ? row : M - 1;
+        rclamp[it] = row < M ? row : M - 1;
+    }
+    // (FP4_ABL_* are ablation switches for tools/exp_gemv.hip only - never defined in the library build)
+    auto load_x = [&](int g) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#ifdef FP4_ABL_NOX
+            xraw[g][q] = u32x4{uint32_t(cidx[g]), 0x3c003c00u, uint32_t(q), 0x3c003c00u};
+#else
+            xraw[g][q] = reinterpret_cast<const u32x4 *>(x)[cidx[g] * 4 + q];
+#endif
+        }
+    };
+    auto load_w = [&](int it, int g) {
+        const int64_t chunk = int64_t(rclamp[it]) * C + cidx[g];
+        wq[it][g] = __builtin_nontemporal_load(Wv + chunk);
+#ifdef FP4_ABL_NOABSMAX
+        const float a = 0.5f;
+#else
+        const float a = absmax[(chunk << 5) >> bs_shift];
+#endif
+        am[it][g] = live[g] ? a : 0.0f;
+    };
+    if constexpr (GMAJOR) {
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-            const int64_t chunk = int64_t(rclamp) * C + cidx[g];
-            wq[it][g] = __builtin_nontemporal_load(Wv + chunk);
-            const float a = absmax[(chunk << 5) >> bs_shift];
-            am[it][g] = live[g] ? a : 0.0f;
+            load_x(g);
+#pragma unroll
+            for (int it = 0; it < ITERS; ++it) load_w(it, g);
+        }
+    } else {
+#pragma unroll
+        for (int g = 0; g < G; ++g) load_x(g);
+        // 2. the whole weight stream of this lane, issued up front
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) load_w(it, g);
         }
     }
     // permute x to decode8's pairing: (x0,x2) (x4,x6) (x1,x3) (x5,x7) per group of 8
     u32x4 xd[G][4];
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
+    auto permute_x = [&](int g) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const u32x4 w = xraw[g][q];
@@ -310,25 +339,55 @@ __global__ __launch_bounds__(WAVES * 64) void gemv16_regx_kernel(const uint16_t 
             xd[g][q].z = perm(w.y, w.x, 0x07060302u);
             xd[g][q].w = perm(w.w, w.z, 0x07060302u);
         }
-    }
-    // 3. decode + dot, one row per half-wave per iteration
+    };
+    if constexpr (!GMAJOR) {
 #pragma unroll
-    for (int it = 0; it < ITERS; ++it) {
-        float p = 0.0f;
+        for (int g = 0; g < G; ++g) permute_x(g);
+    }
+    // 3. decode + dot, one row per half-wave per iteration (consumed in the order the loads were issued; the sum
+    //    over g of each row is accumulated in the same order either way)
+    float pacc[ITERS];
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) pacc[it] = 0.0f;
+    auto consume = [&](int it, int g) {
+        float s[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#ifdef FP4_ABL_NOCOMPUTE
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s[q] = __builtin_bit_cast(float, (wq[it][g][q] ^ xd[g][q].x) & 0x3fffffffu);
+#else
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            uint32_t P[4];
+            decode8<DT>(wq[it][g][q], P);
+            s[q] = dot2<DT>(P[0], xd[g][q].x, s[q]);
+            s[q] = dot2<DT>(P[1], xd[g][q].y, s[q]);
+            s[q] = dot2<DT>(P[2], xd[g][q].z, s[q]);
+            s[q] = dot2<DT>(P[3], xd[g][q].w, s[q]);
+        }
+#endif
+        pacc[it] = __builtin_fmaf((s[0] + s[1]) + (s[2] + s[3]), am[it][g], pacc[it]);
+    };
+    if constexpr (GMAJOR) {
+        // group by group, fenced: without the fence hipcc hoists every group's x permutes above the first dot2, i.e.
+        // waits for almost the whole stream before it starts, and the load phase and the VALU phase of all the
+        // (same-phase) waves of the chip serialise
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-            float s[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            permute_x(g);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                uint32_t P[4];
-                decode8<DT>(wq[it][g][q], P);
-                s[q] = dot2<DT>(P[0], xd[g][q].x, s[q]);
-                s[q] = dot2<DT>(P[1], xd[g][q].y, s[q]);
-                s[q] = dot2<DT>(P[2], xd[g][q].z, s[q]);
-                s[q] = dot2<DT>(P[3], xd[g][q].w, s[q]);
-            }
-            p = __builtin_fmaf((s[0] + s[1]) + (s[2] + s[3]), am[it][g], p);
+            for (int it = 0; it < ITERS; ++it) consume(it, g);
+            __builtin_amdgcn_sched_barrier(0);
         }
+    } else {
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) consume(it, g);
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        float p = pacc[it];
         // sum over the 32 lanes of this half-wave
         p = dpp_add<0x128>(p);
         p = dpp_add<0x124>(p);
@@ -1055,6 +1114,22 @@ int dispatch_regx(int iters, int ks_override, const void *x, const uint8_t *W, c
         if (iters == 1) return launch_regx<DT, 4, 1, 1, 8>(x, W, absmax, bias, out, M, K, bs_shift, out_f32, stream);
         if (iters == 2) return launch_regx<DT, 4, 1, 2, 8>(x, W, absmax, bias, out, M, K, bs_shift, out_f32, stream);
         if (iters == 4) return launch_regx<DT, 4, 1, 4, 8>(x, W, absmax, bias, out, M, K, bs_shift, out_f32, stream);
+    }
+    if (ks_override == 8 && C > 128) {  // sweep hook: K split 8 ways over 8 waves (long rows)
+        const int need8 = (C + 255) / 256;
+        if (need8 <= 1) {
+            if (iters == 1) return launch_regx<DT, 8, 1, 1, 8>(x, W, absmax, bias, out, M, K, bs_shift, out_f32, stream);
+            if (iters == 2) return launch_regx<DT, 8, 1, 2, 8>(x, W, absmax, bias, out, M, K, bs_shift, out_f32, stream);
+            return launch_regx<DT, 8, 1, 4, 8>(x, W, absmax, bias, out, M, K, bs_shift, out_f32, stream);
+        } else if (need8 <= 2) {
+            if (iters == 1) return launch_regx<DT, 8, 2, 1, 8>(x, W, absmax, bias, out, M, K, bs_shift, out_f32, stream);
+            if (iters == 2) return launch_regx<DT, 8, 2, 2, 8>(x, W, absmax, bias, out, M, K, bs_shift, out_f32, stream);
+            return launch_regx<DT, 8, 2, 4, 8>(x, W, absmax, bias, out, M, K, bs_shift, out_f32, stream);
+        } else if (need8 <= 4) {
+            if (iters == 1) return launch_regx<DT, 8, 4, 1, 8>(x, W, absmax, bias, out, M, K, bs_shift, out_f32, stream);
+            return launch_regx<DT, 8, 4, 2, 8>(x, W, absmax, bias, out, M, K, bs_shift, out_f32, stream);
+        }
+        return -1;
     }
     int ks = C <= 32 ? 1 : (C <= 64 ? 2 : 4);
     if (ks_override == 1 || ks_override == 2 || ks_override == 4) ks = ks_override;
