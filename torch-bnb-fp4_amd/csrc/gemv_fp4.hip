@@ -865,19 +865,38 @@ __device__ __forceinline__ f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
 }
 
-template <int DT, int NBW, int ROWT, bool STAGE>
+template <int DT, int NBW, int ROWT, bool STAGE, int XS = 0>
 __global__ __launch_bounds__(512) void gemm16_mfma_kernel(const uint16_t *__restrict__ x, const uint8_t *__restrict__ W,
                                                           const float *__restrict__ absmax,
                                                           const uint16_t *__restrict__ bias, uint16_t *__restrict__ out,
                                                           int B, int M, int K) {
     // ROWT 16-row tiles per workgroup share one B fragment (x slice): x is re-read by every workgroup, so taller
     // workgroups cut that L2 traffic (B*K*2 bytes each) at the price of fewer workgroups
-    __shared__ __attribute__((aligned(16))) float s_part[8][ROWT][256];
     // STAGE: the A-fragment layout wants 8 bytes per lane from 16 different rows (32-byte segments per row per
     // instruction); instead each wave pulls its 16 x (32*NBW)-byte region with row-contiguous 16-byte loads and
-    // re-reads it from a padded, bank-conflict-free LDS image (wave-private: no workgroup barrier)
-    constexpr int kStageStride = 32 * NBW + 16;
-    __shared__ __attribute__((aligned(16))) uint8_t s_w[STAGE ? 8 * ROWT * 16 * kStageStride : 16];
+    // re-reads it from a wave-private LDS image (no workgroup barrier).  Each image row is followed by that row's NBW
+    // block scales: the accumulator layout needs the scales of 4 rows x NBW blocks per lane, the same values in 16 lanes,
+    // so they are fetched once per wave (one 4- or 8-byte load per lane) and re-read from LDS as broadcasts instead of
+    // 8 x 16-byte global loads per lane and tile.  Row stride 32*NBW + 32 bytes: the 8-byte fragment reads of 16 rows
+    // x 4 k-groups fall on distinct banks per half-wave.
+    // XS > 0 (batch <= XS, XS in {4, 8}): the B fragment wants 32 bytes per lane from 16 activation rows, of which only
+    // `batch` are real - loaded straight from global every 16-row workgroup would pull 16 / batch times its share of x
+    // through the texture path (4x the weight stream at batch 4).  Instead the wave copies the XS x (64*NBW) activations of
+    // its K slice into a wave-private LDS image with row-contiguous 16-byte loads and reads the fragments from there
+    // (lanes of the unused columns read a real row: broadcast, results never stored).
+    constexpr int kStageStride = 32 * NBW + 32;
+    constexpr int kXStride = 128 * NBW + 16;
+    constexpr int kWImageBytes = STAGE ? 8 * ROWT * 16 * kStageStride : 0;
+    constexpr int kXImageBytes = 8 * XS * kXStride;
+    constexpr int kImageBytes = kWImageBytes + kXImageBytes;
+    constexpr int kPartBytes = 8 * ROWT * 256 * 4;
+    static_assert(XS == 0 || (STAGE && (XS * NBW) % 8 == 0 && (XS & (XS - 1)) == 0), "x staging: whole 16-byte units per lane");
+    // the cross-wave partial sums reuse the images' storage after the K loop (one barrier in between): LDS per workgroup
+    // decides how many of these 8-wave workgroups a CU holds
+    __shared__ __attribute__((aligned(16))) uint8_t s_raw[kImageBytes > kPartBytes ? kImageBytes : kPartBytes];
+    uint8_t *s_w = s_raw;
+    uint8_t *s_x = s_raw + kWImageBytes;
+    float (*s_part)[ROWT][256] = reinterpret_cast<float (*)[ROWT][256]>(s_raw);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -902,12 +921,23 @@ __global__ __launch_bounds__(512) void gemm16_mfma_kernel(const uint16_t *__rest
     for (int p = 0; p < passes; ++p) {
         const int b0 = (p * 8 + wave) * NBW;
         // x first (L2), then the weight stream (HBM), then the scales; all branch-free
-        u32x4 xr[NBW][2];
+        u32x4 xr[XS ? 1 : NBW][2];
+        constexpr int kXUnits = XS ? XS * NBW / 8 : 1;  // 16-byte units of the x image per lane
+        u32x4 xstage[kXUnits];
+        if constexpr (XS > 0) {
 #pragma unroll
-        for (int j = 0; j < NBW; ++j) {
-            const int64_t e = n_b * K + 64 * (b0 + j) + 16 * kb;
-            xr[j][0] = x4[e >> 3];
-            xr[j][1] = x4[(e >> 3) + 1];
+            for (int i = 0; i < kXUnits; ++i) {
+                const int u = i * 64 + lane, n = u / (8 * NBW), c16 = u % (8 * NBW);
+                const int64_t nn = n < B ? n : B - 1;
+                xstage[i] = x4[((nn * K + 64 * b0) >> 3) + c16];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NBW; ++j) {
+                const int64_t e = n_b * K + 64 * (b0 + j) + 16 * kb;
+                xr[j][0] = x4[e >> 3];
+                xr[j][1] = x4[(e >> 3) + 1];
+            }
         }
         u32x2 wq[ROWT][NBW];
         constexpr int kLanesPerRow = 2 * NBW, kRowsPerInstr = 64 / kLanesPerRow, kInstr = (16 + kRowsPerInstr - 1) / kRowsPerInstr;
@@ -930,20 +960,35 @@ __global__ __launch_bounds__(512) void gemm16_mfma_kernel(const uint16_t *__rest
                     wq[rt][j] = __builtin_nontemporal_load(W2 + ((row_a[rt] * K) >> 4) + 4 * (b0 + j) + kb);
         }
         float am[ROWT][4][NBW];
+        // 16 rows x NBW scales over 64 lanes (with NBW < 4 the upper lanes repeat rows: same address, same value)
+        constexpr int kScalesPerLane = NBW > 4 ? NBW / 4 : 1;
+        constexpr int kLanesPerScaleRow = NBW / kScalesPerLane;
+        const int srow = (lane / kLanesPerScaleRow) & 15, sj0 = (lane % kLanesPerScaleRow) * kScalesPerLane;
+        float amstage[ROWT][kScalesPerLane];
+        if constexpr (STAGE) {
 #pragma unroll
-        for (int rt = 0; rt < ROWT; ++rt) {
+            for (int rt = 0; rt < ROWT; ++rt) {
+                const int64_t row = row0 + 16 * rt + srow < M ? row0 + 16 * rt + srow : M - 1;
+                const float *src = absmax + row * nblk + b0 + sj0;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float *src = absmax + row_d[rt][g] * nblk + b0;
-                if constexpr (NBW % 4 == 0) {
+                for (int i = 0; i < kScalesPerLane; ++i) amstage[rt][i] = src[i];
+            }
+        } else {
 #pragma unroll
-                    for (int j = 0; j < NBW; j += 4) {
-                        const f32x4 v = *reinterpret_cast<const f32x4 *>(src + j);
-                        am[rt][g][j] = v.x, am[rt][g][j + 1] = v.y, am[rt][g][j + 2] = v.z, am[rt][g][j + 3] = v.w;
+            for (int rt = 0; rt < ROWT; ++rt) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float *src = absmax + row_d[rt][g] * nblk + b0;
+                    if constexpr (NBW % 4 == 0) {
+#pragma unroll
+                        for (int j = 0; j < NBW; j += 4) {
+                            const f32x4 v = *reinterpret_cast<const f32x4 *>(src + j);
+                            am[rt][g][j] = v.x, am[rt][g][j + 1] = v.y, am[rt][g][j + 2] = v.z, am[rt][g][j + 3] = v.w;
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < NBW; ++j) am[rt][g][j] = src[j];
                     }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < NBW; ++j) am[rt][g][j] = src[j];
                 }
             }
         }
@@ -957,6 +1002,17 @@ __global__ __launch_bounds__(512) void gemm16_mfma_kernel(const uint16_t *__rest
                     const int rr = i * kRowsPerInstr + lane / kLanesPerRow;
                     if (rr < 16) *reinterpret_cast<u32x4 *>(img + rr * kStageStride + 16 * (lane % kLanesPerRow)) = wstage[rt][i];
                 }
+                float *tail = reinterpret_cast<float *>(img + srow * kStageStride + 32 * NBW) + sj0;
+#pragma unroll
+                for (int i = 0; i < kScalesPerLane; ++i) tail[i] = amstage[rt][i];
+            }
+            if constexpr (XS > 0) {
+                uint8_t *ximg = s_x + wave * XS * kXStride;
+#pragma unroll
+                for (int i = 0; i < kXUnits; ++i) {
+                    const int u = i * 64 + lane, n = u / (8 * NBW), c16 = u % (8 * NBW);
+                    *reinterpret_cast<u32x4 *>(ximg + n * kXStride + 16 * c16) = xstage[i];
+                }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -966,6 +1022,20 @@ __global__ __launch_bounds__(512) void gemm16_mfma_kernel(const uint16_t *__rest
                 const uint8_t *img = s_w + (wave * ROWT + rt) * 16 * kStageStride;
 #pragma unroll
                 for (int j = 0; j < NBW; ++j) wq[rt][j] = *reinterpret_cast<const u32x2 *>(img + r * kStageStride + 32 * j + 8 * kb);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const uint8_t *src = img + (kb * 4 + g) * kStageStride + 32 * NBW;
+                    if constexpr (NBW % 4 == 0) {
+#pragma unroll
+                        for (int j = 0; j < NBW; j += 4) {
+                            const f32x4 v = reinterpret_cast<const f32x4 *>(src)[j >> 2];
+                            am[rt][g][j] = v.x, am[rt][g][j + 1] = v.y, am[rt][g][j + 2] = v.z, am[rt][g][j + 3] = v.w;
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < NBW; ++j) am[rt][g][j] = reinterpret_cast<const float *>(src)[j];
+                    }
+                }
             }
         }
 #pragma unroll
@@ -973,7 +1043,11 @@ __global__ __launch_bounds__(512) void gemm16_mfma_kernel(const uint16_t *__rest
             u32x4 bfrag[2];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                const u32x4 w = xr[j][t];
+                u32x4 w;
+                if constexpr (XS > 0)
+                    w = *reinterpret_cast<const u32x4 *>(s_x + wave * XS * kXStride + (r & (XS - 1)) * kXStride + 128 * j + 32 * kb + 16 * t);
+                else
+                    w = xr[j][t];
                 bfrag[t].x = perm(w.y, w.x, 0x05040100u);  // (x0,x2)
                 bfrag[t].y = perm(w.w, w.z, 0x05040100u);  // (x4,x6)
                 bfrag[t].z = perm(w.y, w.x, 0x07060302u);  // (x1,x3)
@@ -996,6 +1070,7 @@ __global__ __launch_bounds__(512) void gemm16_mfma_kernel(const uint16_t *__rest
             }
         }
     }
+    if constexpr (STAGE) __syncthreads();  // every wave is done with its image before the partials overwrite the storage
 #pragma unroll
     for (int rt = 0; rt < ROWT; ++rt) *reinterpret_cast<f32x4 *>(&s_part[wave][rt][lane * 4]) = acc[rt];
     __syncthreads();
@@ -1016,21 +1091,41 @@ __global__ __launch_bounds__(512) void gemm16_mfma_kernel(const uint16_t *__rest
 
 int g_mfma_rowt = -1;   // sweeps: force 1 or 2 row tiles per workgroup
 int g_mfma_stage = -1;  // sweeps: 0 = direct 8-byte weight loads, otherwise LDS-staged 16-byte loads
+int g_mfma_xstage = -1;  // sweeps: 0 = B fragments straight from global even for batch <= 8
 
 template <int DT>
 int dispatch_mfma(const void *x, const uint8_t *W, const float *absmax, const void *bias, void *out, int B, int M, int K,
                   hipStream_t stream) {
     if (K % 512) return -1;
     const int units = K / 512;  // quant blocks per wave over the whole K
-    // two row tiles per workgroup once that still leaves >= 256 workgroups (one per CU)
-    const int rowt = g_mfma_rowt > 0 ? g_mfma_rowt : (M >= 32 * 256 ? 2 : 1);
+    // Measured (profiles/r01_f_small_batch_shapes.txt): two row tiles per workgroup (x fetched once per 32 rows) only pay
+    // for more than 4 activation rows on tall weights; at 188 VGPRs they leave one 8-wave workgroup per CU.
+    const int rowt = g_mfma_rowt > 0 ? g_mfma_rowt : ((B > 4 && M >= 32 * 256) ? 2 : 1);
     const unsigned blocks = (unsigned)((M + 16 * rowt - 1) / (16 * rowt));
+    // x staged per wave in LDS: always for <= 4 rows (33 KB, two workgroups per CU still fit); for 5..8 rows (66 KB, one
+    // workgroup per CU) only while the grid is a single round anyway
+    const bool xs4 = g_mfma_xstage != 0 && B <= 4;
+    const bool xs8 = g_mfma_xstage != 0 && !xs4 && B <= 8 && (int)blocks <= device_cu_count();
 #define FP4_MF(NBW, RT)                                                                                               \
     if (g_mfma_stage == 0) {                                                                                          \
         hipLaunchKernelGGL((gemm16_mfma_kernel<DT, NBW, RT, false>), dim3(blocks), dim3(512), 0, stream,              \
                            reinterpret_cast<const uint16_t *>(x), W, absmax, reinterpret_cast<const uint16_t *>(bias), \
                            reinterpret_cast<uint16_t *>(out), B, M, K);                                               \
         return FP4_OK;                                                                                                \
+    }                                                                                                                 \
+    if constexpr ((NBW) >= 4) {                                                                                       \
+        if (xs4) {                                                                                                    \
+            hipLaunchKernelGGL((gemm16_mfma_kernel<DT, NBW, RT, true, 4>), dim3(blocks), dim3(512), 0, stream,        \
+                               reinterpret_cast<const uint16_t *>(x), W, absmax,                                      \
+                               reinterpret_cast<const uint16_t *>(bias), reinterpret_cast<uint16_t *>(out), B, M, K); \
+            return FP4_OK;                                                                                            \
+        }                                                                                                             \
+        if (xs8) {                                                                                                    \
+            hipLaunchKernelGGL((gemm16_mfma_kernel<DT, NBW, RT, true, 8>), dim3(blocks), dim3(512), 0, stream,        \
+                               reinterpret_cast<const uint16_t *>(x), W, absmax,                                      \
+                               reinterpret_cast<const uint16_t *>(bias), reinterpret_cast<uint16_t *>(out), B, M, K); \
+            return FP4_OK;                                                                                            \
+        }                                                                                                             \
     }                                                                                                                 \
     hipLaunchKernelGGL((gemm16_mfma_kernel<DT, NBW, RT, true>), dim3(blocks), dim3(512), 0, stream,                   \
                        reinterpret_cast<const uint16_t *>(x), W, absmax, reinterpret_cast<const uint16_t *>(bias),    \
@@ -1187,6 +1282,7 @@ void set_small_variant(int v) {
     g_mfma_rowt = v < 0 ? -1 : ((v >> 4) & 3);  // bits 4-5: row tiles per workgroup of the matrix-core kernel (0 = auto)
     if (g_mfma_rowt == 0) g_mfma_rowt = -1;
     g_mfma_stage = v < 0 ? -1 : ((v >> 8) & 1 ? 0 : 1);  // bit 8: direct (unstaged) weight loads
+    g_mfma_xstage = v < 0 ? -1 : ((v >> 9) & 1 ? 0 : 1);  // bit 9: B fragments straight from global
 }
 
 }  // namespace fp4
@@ -1299,7 +1395,8 @@ extern "C" int fp4_hip_gemm_small(const void *x, const uint8_t *packed, const fl
     int rc = -1;
     // matrix-core kernel: blocksize 64, K % 512 == 0; wins from 3 rows up (5.6 vs 6.8 us at 3, 6.4 vs 11.4 us at 8), mandatory above 8
     const bool mfma_ok = ok && blocksize == 64 && (K % 512) == 0;
-    const bool want_mfma = g_small_variant == 1 || (g_small_variant < 0 && B >= 3);
+    // (long rows, K >= 8192: already at 1-2 rows, 11.8 vs 14.0 us at 4096 x 14336)
+    const bool want_mfma = g_small_variant == 1 || (g_small_variant < 0 && (B >= 3 || K >= 8192));
     if (mfma_ok && (want_mfma || B > 8))
         rc = dtype == FP4_DTYPE_F16 ? dispatch_mfma<FP4_DTYPE_F16>(x, packed, absmax, bias, out, (int)B, (int)M, (int)K, s)
                                     : dispatch_mfma<FP4_DTYPE_BF16>(x, packed, absmax, bias, out, (int)B, (int)M, (int)K, s);
