@@ -59,6 +59,8 @@ class Lib:
         self.l.fp4_hip_dequantize_blockwise.argtypes = [vp, vp, vp, i32, i64, i32, i32, i32, vp]
         self.l.fp4_hip_gemv.argtypes = [vp, vp, vp, vp, vp, i64, i64, i32, i32, vp]
         self.l.fp4_hip_gemv_partial.argtypes = [vp, vp, vp, vp, i64, i64, i32, i32, vp]
+        self.l.fp4_hip_gemm_small.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, i32, i32, vp]
+        self.l.fp4_hip_quantize_blockwise.argtypes = [vp, i32, vp, vp, i64, i32, vp]
         self.l.fp4_hip_last_error.restype = ctypes.c_char_p
 
     def _check(self, rc):
@@ -72,6 +74,14 @@ class Lib:
     def gemv(self, x, packed, absmax, out, m, k, dtype=BF16):
         s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         self._check(self.l.fp4_hip_gemv(x.data_ptr(), packed.data_ptr(), absmax.data_ptr(), None, out.data_ptr(), m, k, BLOCKSIZE, dtype, s))
+
+    def gemm_small(self, x, packed, absmax, out, b, m, k, dtype=BF16):
+        s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        self._check(self.l.fp4_hip_gemm_small(x.data_ptr(), packed.data_ptr(), absmax.data_ptr(), None, out.data_ptr(), b, m, k, BLOCKSIZE, dtype, s))
+
+    def quantize(self, w, packed, absmax, n, dtype=BF16):
+        s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        self._check(self.l.fp4_hip_quantize_blockwise(w.data_ptr(), dtype, packed.data_ptr(), absmax.data_ptr(), n, BLOCKSIZE, s))
 
 
 def tp_ksplit_leg(lib, dist, backend, rank, world, dev, x, packed0, absmax0, barrier):
@@ -312,6 +322,22 @@ def main():
                 extra[f"dequant_{name}_us"] = round(us, 3)
                 extra[f"dequant_{name}_gbps"] = round(dequant_bytes(M, K, BLOCKSIZE, o32[0].element_size()) / us / 1e3, 1)
                 del o32, rp
+            # the rows SURVEY 8(f) marks "next", HBM-cold like the headline: fused small batch (2..16 activation rows,
+            # same weight traffic as the GEMV) and the quantiser (reads the bf16 weights the dequant above just wrote)
+            sb = {}
+            for b in (2, 4, 8, 16):
+                xb = torch.randn(b, K, device=dev).to(torch.bfloat16)
+                yb = torch.empty(b, M, dtype=torch.bfloat16, device=dev)
+                rp = capture(lambda: [lib.gemm_small(xb, packed[i], absmax[i], yb, b, M, K) for i in range(R)])
+                sb[str(b)] = round(time_replays(rp, 5, R)[0], 3)
+                del rp
+            extra["small_batch_us_by_rows"] = sb
+            qp, qa = torch.empty(n // 2, dtype=torch.uint8, device=dev), torch.empty(n // BLOCKSIZE, dtype=torch.float32, device=dev)
+            rp = capture(lambda: [lib.quantize(outs[i % len(outs)], qp, qa, n) for i in range(R)])
+            us = time_replays(rp, 5, R)[0]
+            extra["quantize_bf16_us"] = round(us, 3)
+            extra["quantize_bf16_gbps"] = round(dequant_bytes(M, K, BLOCKSIZE, 2) / us / 1e3, 1)
+            del rp, qp, qa
             # launch-overhead-free context: the same kernels on one tall stack of R weights ([R*4096, 4096]) in ONE launch
             # (input buffers are re-used as views; nothing new is read from the host)
             big_p, big_a = torch.cat(packed), torch.cat(absmax)
