@@ -228,6 +228,39 @@ def test_small_batch_fused_gemm(dtype, kernel, B, M, K):
         assert (err <= HALF_ULP[dtype] * 1.01 * np.abs(exact) + 1e-5 * scale + 1e-30).all(), (b, err.max())
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B", [1, 2, 3, 4, 5, 7, 8])
+@pytest.mark.parametrize("M", [33, 1024, 4096, 8200, 20000])
+def test_small_batch_persistent_kernel(dtype, B, M):
+    """The persistent matrix-core kernel (K = 4096, <= 8 rows; by default only on tall weights) forced at every size:
+    fewer tiles than workgroups, exactly one tile each, ragged last tile, and several tiles per workgroup (M = 20000:
+    1250 tiles over 512 / 256 workgroups, i.e. the prefetch-next-tile loop).  Same bar as every other small-batch kernel, and
+    bit-identical to the one-shot kernel (same tile arithmetic, same summation order)."""
+    K = 4096
+    packed, am, _ = make_case(M, K, seed=B * 77 + M)
+    rng = np.random.default_rng(B + M)
+    x = rng.standard_normal((B, K)).astype(np.float32)
+    bias = rng.standard_normal(M).astype(np.float32) * 0.1
+    x_t, b_t = torch_values(x, dtype), torch_values(bias, dtype)
+    P, A = to_dev(packed), to_dev(am)
+    try:
+        hipabi.set_variant("gemm_small", 1 | (2 << 10))
+        y = hipabi.gemm_small(x_t, P, A, M, K, 64, bias=b_t)
+        hipabi.set_variant("gemm_small", 1 | (1 << 10) | (1 << 4))
+        y_one_shot = hipabi.gemm_small(x_t, P, A, M, K, 64, bias=b_t)
+    finally:
+        hipabi.set_variant("gemm_small", -1)
+    assert torch.equal(y, y_one_shot)
+    wabs = np.abs(o.dequantize_f32(packed, am, 64, M * K).reshape(M, K).astype(np.float64))
+    bv = b_t.float().cpu().numpy().astype(np.float64)
+    for b in range(B):
+        xv = x_t[b].float().cpu().numpy().astype(np.float64)
+        exact = c_oracle.gemv_f64(xv, packed, am, M, K, 64) + bv
+        scale = wabs @ np.abs(xv) + np.abs(bv)
+        err = np.abs(y[b].float().cpu().numpy() - exact)
+        assert (err <= HALF_ULP[dtype] * 1.01 * np.abs(exact) + 1e-5 * scale + 1e-30).all(), (b, err.max())
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_unaligned_operands_take_the_generic_path(dtype):
     M, K = 48, 1024

@@ -865,6 +865,16 @@ __device__ __forceinline__ f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
 }
 
+// 8 consecutive 16-bit activations (x0..x7) -> the dword order decode8's pairs multiply with: (x0,x2) (x4,x6) (x1,x3) (x5,x7)
+__device__ __forceinline__ u32x4 pair_up8(u32x4 w) {
+    u32x4 o;
+    o.x = perm(w.y, w.x, 0x05040100u);
+    o.y = perm(w.w, w.z, 0x05040100u);
+    o.z = perm(w.y, w.x, 0x07060302u);
+    o.w = perm(w.w, w.z, 0x07060302u);
+    return o;
+}
+
 template <int DT, int NBW, int ROWT, bool STAGE, int XS = 0>
 __global__ __launch_bounds__(512) void gemm16_mfma_kernel(const uint16_t *__restrict__ x, const uint8_t *__restrict__ W,
                                                           const float *__restrict__ absmax,
@@ -1011,7 +1021,7 @@ __global__ __launch_bounds__(512) void gemm16_mfma_kernel(const uint16_t *__rest
 #pragma unroll
                 for (int i = 0; i < kXUnits; ++i) {
                     const int u = i * 64 + lane, n = u / (8 * NBW), c16 = u % (8 * NBW);
-                    *reinterpret_cast<u32x4 *>(ximg + n * kXStride + 16 * c16) = xstage[i];
+                    *reinterpret_cast<u32x4 *>(ximg + n * kXStride + 16 * c16) = pair_up8(xstage[i]);  // once, not per tile
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1043,15 +1053,10 @@ __global__ __launch_bounds__(512) void gemm16_mfma_kernel(const uint16_t *__rest
             u32x4 bfrag[2];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                u32x4 w;
                 if constexpr (XS > 0)
-                    w = *reinterpret_cast<const u32x4 *>(s_x + wave * XS * kXStride + (r & (XS - 1)) * kXStride + 128 * j + 32 * kb + 16 * t);
+                    bfrag[t] = *reinterpret_cast<const u32x4 *>(s_x + wave * XS * kXStride + (r & (XS - 1)) * kXStride + 128 * j + 32 * kb + 16 * t);
                 else
-                    w = xr[j][t];
-                bfrag[t].x = perm(w.y, w.x, 0x05040100u);  // (x0,x2)
-                bfrag[t].y = perm(w.w, w.z, 0x05040100u);  // (x4,x6)
-                bfrag[t].z = perm(w.y, w.x, 0x07060302u);  // (x1,x3)
-                bfrag[t].w = perm(w.w, w.z, 0x07060302u);  // (x5,x7)
+                    bfrag[t] = pair_up8(xr[j][t]);
             }
 #pragma unroll
             for (int rt = 0; rt < ROWT; ++rt) {
@@ -1089,9 +1094,142 @@ __global__ __launch_bounds__(512) void gemm16_mfma_kernel(const uint16_t *__rest
     }
 }
 
+// ---- the same tile arithmetic as a PERSISTENT workgroup, for K = 4096 (one pass: 8 waves x 8 blocks) -------------
+// On tall weights the one-shot kernel above runs as three to four generations of 8-wave workgroups, each of which has
+// nothing in flight while it stages, decodes and reduces.  Here a workgroup walks 16-row tiles with stride gridDim.x:
+//   * a wave keeps the same K slice for every tile, so its XS x (512) activations are staged ONCE into its LDS image;
+//   * the next tile's weights and scales (4 + 1 loads per lane) are issued right after the current tile's registers have
+//     been written to the weight image, and fly while the current tile is decoded, multiplied, reduced and stored.
+template <int DT, int XS>
+__global__ __launch_bounds__(512) void gemm16_mfma_persist_kernel(const uint16_t *__restrict__ x, const uint8_t *__restrict__ W,
+                                                                  const float *__restrict__ absmax,
+                                                                  const uint16_t *__restrict__ bias, uint16_t *__restrict__ out,
+                                                                  int B, int M, int K, int ntiles) {
+    constexpr int NBW = 8;
+    constexpr int kStageStride = 32 * NBW + 32, kXStride = 128 * NBW + 16;
+    constexpr int kXUnits = XS * NBW / 8;
+    __shared__ __attribute__((aligned(16))) uint8_t s_w[8 * 16 * kStageStride];
+    __shared__ __attribute__((aligned(16))) uint8_t s_x[8 * XS * kXStride];
+    __shared__ __attribute__((aligned(16))) float s_part[8][256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, kb = lane >> 4;
+    const int nblk = K >> 6;
+    const int b0 = wave * NBW;
+    const u32x4 *x4 = reinterpret_cast<const u32x4 *>(x);
+    uint8_t *img = s_w + wave * 16 * kStageStride;
+    uint8_t *ximg = s_x + wave * XS * kXStride;
+
+    // x slice of this wave, once
+    {
+        u32x4 xstage[kXUnits];
+#pragma unroll
+        for (int i = 0; i < kXUnits; ++i) {
+            const int u = i * 64 + lane, n = u / (8 * NBW), c16 = u % (8 * NBW);
+            const int64_t nn = n < B ? n : B - 1;
+            xstage[i] = x4[((nn * K + 64 * b0) >> 3) + c16];
+        }
+#pragma unroll
+        for (int i = 0; i < kXUnits; ++i) {
+            const int u = i * 64 + lane, n = u / (8 * NBW), c16 = u % (8 * NBW);
+            *reinterpret_cast<u32x4 *>(ximg + n * kXStride + 16 * c16) = pair_up8(xstage[i]);
+        }
+    }
+
+    constexpr int kLanesPerRow = 2 * NBW, kRowsPerInstr = 64 / kLanesPerRow, kInstr = 16 / kRowsPerInstr;  // 16, 4, 4
+    constexpr int kScalesPerLane = NBW / 4;
+    const int srow = lane >> 2, sj0 = (lane & 3) * kScalesPerLane;
+    u32x4 wstage[kInstr];
+    float amstage[kScalesPerLane];
+    auto issue = [&](int tile) {  // branch-free: rows past M are clamped (computed, never stored)
+        const int row0 = tile * 16;
+#pragma unroll
+        for (int i = 0; i < kInstr; ++i) {
+            const int rr = i * kRowsPerInstr + lane / kLanesPerRow;
+            const int64_t row = row0 + rr < M ? row0 + rr : M - 1;
+            wstage[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(W) + ((row * K) >> 5) + 2 * b0 + (lane % kLanesPerRow));
+        }
+        const int64_t row = row0 + srow < M ? row0 + srow : M - 1;
+        const float *src = absmax + row * nblk + b0 + sj0;
+#pragma unroll
+        for (int i = 0; i < kScalesPerLane; ++i) amstage[i] = src[i];
+    };
+
+    int tile = blockIdx.x;
+    issue(tile);
+    while (true) {
+        __builtin_amdgcn_wave_barrier();  // this wave's reads of the previous tile's image are done
+#pragma unroll
+        for (int i = 0; i < kInstr; ++i) {
+            const int rr = i * kRowsPerInstr + lane / kLanesPerRow;
+            *reinterpret_cast<u32x4 *>(img + rr * kStageStride + 16 * (lane % kLanesPerRow)) = wstage[i];
+        }
+        {
+            float *tail = reinterpret_cast<float *>(img + srow * kStageStride + 32 * NBW) + sj0;
+#pragma unroll
+            for (int i = 0; i < kScalesPerLane; ++i) tail[i] = amstage[i];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+        const int next = tile + gridDim.x;
+        const bool has_next = next < ntiles;  // uniform
+        if (has_next) issue(next);
+
+        u32x2 wq[NBW];
+        float am[4][NBW];
+#pragma unroll
+        for (int j = 0; j < NBW; ++j) wq[j] = *reinterpret_cast<const u32x2 *>(img + r * kStageStride + 32 * j + 8 * kb);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 *src = reinterpret_cast<const f32x4 *>(img + (kb * 4 + g) * kStageStride + 32 * NBW);
+#pragma unroll
+            for (int j = 0; j < NBW; j += 4) {
+                const f32x4 v = src[j >> 2];
+                am[g][j] = v.x, am[g][j + 1] = v.y, am[g][j + 2] = v.z, am[g][j + 3] = v.w;
+            }
+        }
+        f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int j = 0; j < NBW; ++j) {
+            f32x4 t16 = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const u32x4 bfrag = *reinterpret_cast<const u32x4 *>(ximg + (r & (XS - 1)) * kXStride + 128 * j + 32 * kb + 16 * t);
+                uint32_t P[4];
+                decode8<DT>(t == 0 ? wq[j].x : wq[j].y, P);
+                const u32x4 afrag = {P[0], P[1], P[2], P[3]};
+                t16 = mfma16<DT>(afrag, bfrag, t16);
+            }
+            acc.x = __builtin_fmaf(t16.x, am[0][j], acc.x);
+            acc.y = __builtin_fmaf(t16.y, am[1][j], acc.y);
+            acc.z = __builtin_fmaf(t16.z, am[2][j], acc.z);
+            acc.w = __builtin_fmaf(t16.w, am[3][j], acc.w);
+        }
+        *reinterpret_cast<f32x4 *>(&s_part[wave][lane * 4]) = acc;
+        __syncthreads();
+        if (tid < 256) {
+            float t = 0.0f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) t += s_part[w][tid];
+            const int l = tid >> 2, reg = tid & 3;  // D layout: col = l & 15 (activation row), row = (l >> 4) * 4 + reg
+            const int n = l & 15, row = tile * 16 + (l >> 4) * 4 + reg;
+            if (row < M && n < B) {
+                t *= (1.0f / 12.0f);
+                if (bias) t += to_f32<DT>(bias[row]);
+                out[int64_t(n) * M + row] = from_f32<DT>(t);
+            }
+        }
+        __syncthreads();  // s_part is rewritten by the next tile
+        if (!has_next) break;
+        tile = next;
+    }
+}
+
 int g_mfma_rowt = -1;   // sweeps: force 1 or 2 row tiles per workgroup
 int g_mfma_stage = -1;  // sweeps: 0 = direct 8-byte weight loads, otherwise LDS-staged 16-byte loads
 int g_mfma_xstage = -1;  // sweeps: 0 = B fragments straight from global even for batch <= 8
+int g_mfma_persist = -1;  // sweeps: 0 = never the persistent kernel, 1 = whenever it applies (K = 4096, batch <= 4)
 
 template <int DT>
 int dispatch_mfma(const void *x, const uint8_t *W, const float *absmax, const void *bias, void *out, int B, int M, int K,
@@ -1104,6 +1242,24 @@ int dispatch_mfma(const void *x, const uint8_t *W, const float *absmax, const vo
     const unsigned blocks = (unsigned)((M + 16 * rowt - 1) / (16 * rowt));
     // x staged per wave in LDS: always for <= 4 rows (33 KB, two workgroups per CU still fit); for 5..8 rows (66 KB, one
     // workgroup per CU) only while the grid is a single round anyway
+    if (g_mfma_persist != 0 && g_mfma_rowt <= 0 && g_mfma_stage != 0 && g_mfma_xstage != 0 && K == 4096 && B <= 8) {
+        // tall weights only: with at most two workgroups per CU's worth of tiles there is nothing to pipeline.  Up to 4
+        // rows two workgroups fit a CU (78 KB of LDS each), up to 8 rows one (111 KB).
+        const int ntiles = (M + 15) / 16, resident = (B <= 4 ? 2 : 1) * device_cu_count();
+        // measured break-even (profiles/r01_f_small_batch_shapes.txt): 4 tiles per CU up to 4 rows, 2 above
+        if (g_mfma_persist > 0 || ntiles >= (B <= 4 ? 4 : 2) * device_cu_count()) {
+            const dim3 grid(ntiles < resident ? ntiles : resident);
+            if (B <= 4)
+                hipLaunchKernelGGL((gemm16_mfma_persist_kernel<DT, 4>), grid, dim3(512), 0, stream,
+                                   reinterpret_cast<const uint16_t *>(x), W, absmax, reinterpret_cast<const uint16_t *>(bias),
+                                   reinterpret_cast<uint16_t *>(out), B, M, K, ntiles);
+            else
+                hipLaunchKernelGGL((gemm16_mfma_persist_kernel<DT, 8>), grid, dim3(512), 0, stream,
+                                   reinterpret_cast<const uint16_t *>(x), W, absmax, reinterpret_cast<const uint16_t *>(bias),
+                                   reinterpret_cast<uint16_t *>(out), B, M, K, ntiles);
+            return FP4_OK;
+        }
+    }
     const bool xs4 = g_mfma_xstage != 0 && B <= 4;
     const bool xs8 = g_mfma_xstage != 0 && !xs4 && B <= 8 && (int)blocks <= device_cu_count();
 #define FP4_MF(NBW, RT)                                                                                               \
@@ -1283,6 +1439,7 @@ void set_small_variant(int v) {
     if (g_mfma_rowt == 0) g_mfma_rowt = -1;
     g_mfma_stage = v < 0 ? -1 : ((v >> 8) & 1 ? 0 : 1);  // bit 8: direct (unstaged) weight loads
     g_mfma_xstage = v < 0 ? -1 : ((v >> 9) & 1 ? 0 : 1);  // bit 9: B fragments straight from global
+    g_mfma_persist = v < 0 ? -1 : ((v >> 10) & 3) == 1 ? 0 : (((v >> 10) & 3) == 2 ? 1 : -1);  // bits 10-11: 1 = off, 2 = force
 }
 
 }  // namespace fp4
@@ -1393,10 +1550,9 @@ extern "C" int fp4_hip_gemm_small(const void *x, const uint8_t *packed, const fl
                     (K % blocksize) == 0 && (align & 15u) == 0 && M <= (int64_t(1) << 30) && K <= (int64_t(1) << 24);
     hipStream_t s = static_cast<hipStream_t>(stream);
     int rc = -1;
-    // matrix-core kernel: blocksize 64, K % 512 == 0; wins from 3 rows up (5.6 vs 6.8 us at 3, 6.4 vs 11.4 us at 8), mandatory above 8
+    // matrix-core kernel: blocksize 64, K % 512 == 0; wins from 2 rows up (4.96 vs 5.11 us at 2, 5.0 vs 11.3 us at 8), mandatory above 8
     const bool mfma_ok = ok && blocksize == 64 && (K % 512) == 0;
-    // (long rows, K >= 8192: already at 1-2 rows, 11.8 vs 14.0 us at 4096 x 14336)
-    const bool want_mfma = g_small_variant == 1 || (g_small_variant < 0 && (B >= 3 || K >= 8192));
+    const bool want_mfma = g_small_variant == 1 || (g_small_variant < 0 && B >= 2);
     if (mfma_ok && (want_mfma || B > 8))
         rc = dtype == FP4_DTYPE_F16 ? dispatch_mfma<FP4_DTYPE_F16>(x, packed, absmax, bias, out, (int)B, (int)M, (int)K, s)
                                     : dispatch_mfma<FP4_DTYPE_BF16>(x, packed, absmax, bias, out, (int)B, (int)M, (int)K, s);
