@@ -229,10 +229,11 @@ def test_small_batch_fused_gemm(dtype, kernel, B, M, K):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("B", [1, 2, 3, 4, 5, 7, 8])
+@pytest.mark.parametrize("B", [1, 2, 3, 4, 5, 7, 8, 9, 13, 16])
 @pytest.mark.parametrize("M", [33, 1024, 4096, 8200, 20000])
 def test_small_batch_persistent_kernel(dtype, B, M):
-    """The persistent matrix-core kernel (K = 4096, <= 8 rows; by default only on tall weights) forced at every size:
+    """The persistent matrix-core kernel (K = 4096; x image for <= 4 / <= 8 rows, register-resident B fragments above; by
+    default only on tall weights) forced at every size:
     fewer tiles than workgroups, exactly one tile each, ragged last tile, and several tiles per workgroup (M = 20000:
     1250 tiles over 512 / 256 workgroups, i.e. the prefetch-next-tile loop).  Same bar as every other small-batch kernel, and
     bit-identical to the one-shot kernel (same tile arithmetic, same summation order)."""

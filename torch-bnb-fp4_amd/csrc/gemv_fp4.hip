@@ -1107,9 +1107,9 @@ __global__ __launch_bounds__(512) void gemm16_mfma_persist_kernel(const uint16_t
                                                                   int B, int M, int K, int ntiles) {
     constexpr int NBW = 8;
     constexpr int kStageStride = 32 * NBW + 32, kXStride = 128 * NBW + 16;
-    constexpr int kXUnits = XS * NBW / 8;
+    constexpr int kXUnits = XS ? XS * NBW / 8 : 1;
     __shared__ __attribute__((aligned(16))) uint8_t s_w[8 * 16 * kStageStride];
-    __shared__ __attribute__((aligned(16))) uint8_t s_x[8 * XS * kXStride];
+    __shared__ __attribute__((aligned(16))) uint8_t s_x[XS ? 8 * XS * kXStride : 16];
     __shared__ __attribute__((aligned(16))) float s_part[8][256];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, kb = lane >> 4;
@@ -1119,8 +1119,18 @@ __global__ __launch_bounds__(512) void gemm16_mfma_persist_kernel(const uint16_t
     uint8_t *img = s_w + wave * 16 * kStageStride;
     uint8_t *ximg = s_x + wave * XS * kXStride;
 
-    // x slice of this wave, once
-    {
+    // x slice of this wave, once: up to 8 rows as a paired-up LDS image; above that (XS == 0) the 16 B fragments of the slice
+    // stay in registers for every tile (64 VGPRs: one workgroup per CU, but no x traffic at all after the first tile)
+    u32x4 bregs[XS ? 1 : NBW][2];
+    if constexpr (XS == 0) {
+        const int64_t n_b = r < B ? r : B - 1;
+#pragma unroll
+        for (int j = 0; j < NBW; ++j) {
+            const int64_t e = n_b * K + 64 * (b0 + j) + 16 * kb;
+            bregs[j][0] = pair_up8(x4[e >> 3]);
+            bregs[j][1] = pair_up8(x4[(e >> 3) + 1]);
+        }
+    } else {
         u32x4 xstage[kXUnits];
 #pragma unroll
         for (int i = 0; i < kXUnits; ++i) {
@@ -1195,7 +1205,11 @@ __global__ __launch_bounds__(512) void gemm16_mfma_persist_kernel(const uint16_t
             f32x4 t16 = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                const u32x4 bfrag = *reinterpret_cast<const u32x4 *>(ximg + (r & (XS - 1)) * kXStride + 128 * j + 32 * kb + 16 * t);
+                u32x4 bfrag;
+                if constexpr (XS == 0)
+                    bfrag = bregs[j][t];
+                else
+                    bfrag = *reinterpret_cast<const u32x4 *>(ximg + (r & (XS - 1)) * kXStride + 128 * j + 32 * kb + 16 * t);
                 uint32_t P[4];
                 decode8<DT>(t == 0 ? wq[j].x : wq[j].y, P);
                 const u32x4 afrag = {P[0], P[1], P[2], P[3]};
@@ -1242,19 +1256,23 @@ int dispatch_mfma(const void *x, const uint8_t *W, const float *absmax, const vo
     const unsigned blocks = (unsigned)((M + 16 * rowt - 1) / (16 * rowt));
     // x staged per wave in LDS: always for <= 4 rows (33 KB, two workgroups per CU still fit); for 5..8 rows (66 KB, one
     // workgroup per CU) only while the grid is a single round anyway
-    if (g_mfma_persist != 0 && g_mfma_rowt <= 0 && g_mfma_stage != 0 && g_mfma_xstage != 0 && K == 4096 && B <= 8) {
-        // tall weights only: with at most two workgroups per CU's worth of tiles there is nothing to pipeline.  Up to 4
-        // rows two workgroups fit a CU (78 KB of LDS each), up to 8 rows one (111 KB).
+    if (g_mfma_persist != 0 && g_mfma_rowt <= 0 && g_mfma_stage != 0 && g_mfma_xstage != 0 && K == 4096) {
+        // Up to 4 rows two workgroups fit a CU (78 KB of LDS each), above that one (111 KB of LDS / 166 VGPRs).
         const int ntiles = (M + 15) / 16, resident = (B <= 4 ? 2 : 1) * device_cu_count();
-        // measured break-even (profiles/r01_f_small_batch_shapes.txt): 4 tiles per CU up to 4 rows, 2 above
-        if (g_mfma_persist > 0 || ntiles >= (B <= 4 ? 4 : 2) * device_cu_count()) {
+        // measured (profiles/r01_f_small_batch_shapes.txt): never slower than the one-shot kernel, level with it while
+        // every workgroup has a single tile, up to 1.6x faster on tall weights
+        {
             const dim3 grid(ntiles < resident ? ntiles : resident);
             if (B <= 4)
                 hipLaunchKernelGGL((gemm16_mfma_persist_kernel<DT, 4>), grid, dim3(512), 0, stream,
                                    reinterpret_cast<const uint16_t *>(x), W, absmax, reinterpret_cast<const uint16_t *>(bias),
                                    reinterpret_cast<uint16_t *>(out), B, M, K, ntiles);
-            else
+            else if (B <= 8)
                 hipLaunchKernelGGL((gemm16_mfma_persist_kernel<DT, 8>), grid, dim3(512), 0, stream,
+                                   reinterpret_cast<const uint16_t *>(x), W, absmax, reinterpret_cast<const uint16_t *>(bias),
+                                   reinterpret_cast<uint16_t *>(out), B, M, K, ntiles);
+            else
+                hipLaunchKernelGGL((gemm16_mfma_persist_kernel<DT, 0>), grid, dim3(512), 0, stream,
                                    reinterpret_cast<const uint16_t *>(x), W, absmax, reinterpret_cast<const uint16_t *>(bias),
                                    reinterpret_cast<uint16_t *>(out), B, M, K, ntiles);
             return FP4_OK;
