@@ -88,14 +88,16 @@ FP4_HIP_API int fp4_hip_gemv(const void *x, const uint8_t *packed, const float *
                  int64_t K, int blocksize, int dtype, void *stream);
 
 /*
- * Small-batch companion of the GEMV (2..16 activation rows; also accepts 1):
+ * Small-batch companion of the GEMV (2..64 activation rows; also accepts 1; one launch per 16 rows):
  *   out[b][r] = T( sum_k x[b][k] * code[nibble(r,k)] * absmax[(r*K+k)/blocksize] + bias[r] )
  * x is T[B,K] row-major, out T[B,M]; f32 accumulation, ONE rounding, bias added in f32 first (what the
  * reference's batch > 1 path, dequant + F.linear, does - torch_bnb_fp4/__init__.py:423-436,616-617 - without
  * writing and re-reading the M*K dequantised weight).  16-bit dtypes only.  Two kernels: a matrix-core one
  * (v_mfma_f32_16x16x32; blocksize 64, K % 512 == 0; any B <= 16) and a VALU one (B <= 8; K % 32 == 0, K <= 16384,
  * less for larger B; power-of-two blocksize >= 32 dividing K).  Returns FP4_ERR_UNSUPPORTED for shapes neither
- * covers, so the caller can fall back to dequant + GEMM.
+ * covers, so the caller can fall back to dequant + GEMM.  17..64 rows are split evenly over ceil(B/16) launches, each
+ * streaming the weight once (worth it while that is less traffic than writing and re-reading the dequantised weight:
+ * always up to 32 rows, up to 64 on tall weights).
  */
 FP4_HIP_API int fp4_hip_gemm_small(const void *x, const uint8_t *packed, const float *absmax, const void *bias, void *out,
                                    int64_t B, int64_t M, int64_t K, int blocksize, int dtype, void *stream);

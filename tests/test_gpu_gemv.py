@@ -262,6 +262,32 @@ def test_small_batch_persistent_kernel(dtype, B, M):
         assert (err <= HALF_ULP[dtype] * 1.01 * np.abs(exact) + 1e-5 * scale + 1e-30).all(), (b, err.max())
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B", [17, 24, 32, 33, 64])
+@pytest.mark.parametrize("M,K", [(4096, 4096), (300, 8192), (66, 2048)])
+def test_small_batch_beyond_16_rows_is_chunked(dtype, B, M, K):
+    """17..64 rows: evenly split over ceil(B/16) launches; each row of the result equals what a single-chunk call on that row's
+    chunk gives (bit for bit) and meets the GEMV bar against the float64 product.  65 rows are refused."""
+    packed, am, _ = make_case(M, K, seed=B + M)
+    rng = np.random.default_rng(B * 3 + K)
+    x = rng.standard_normal((B, K)).astype(np.float32)
+    x_t = torch_values(x, dtype)
+    P, A = to_dev(packed), to_dev(am)
+    y = hipabi.gemm_small(x_t, P, A, M, K, 64)
+    chunks = -(-B // 16)
+    per = -(-B // chunks)
+    parts = [hipabi.gemm_small(x_t[b0:b0 + per].contiguous(), P, A, M, K, 64) for b0 in range(0, B, per)]
+    assert torch.equal(y, torch.cat(parts))
+    wabs = np.abs(o.dequantize_f32(packed, am, 64, M * K).reshape(M, K).astype(np.float64))
+    for b in (0, 15, 16, B - 1):
+        xv = x_t[b].float().cpu().numpy().astype(np.float64)
+        exact = c_oracle.gemv_f64(xv, packed, am, M, K, 64)
+        err = np.abs(y[b].float().cpu().numpy() - exact)
+        assert (err <= HALF_ULP[dtype] * 1.01 * np.abs(exact) + 1e-5 * (wabs @ np.abs(xv)) + 1e-30).all(), (b, err.max())
+    too_many = torch.zeros(65, K, dtype=dtype, device=dev())
+    assert hipabi.gemm_small(too_many, P, A, M, K, 64, expect_ok=False) == hipabi.ERR_INVALID
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_unaligned_operands_take_the_generic_path(dtype):
     M, K = 48, 1024

@@ -1553,9 +1553,27 @@ extern "C" int fp4_hip_gemv_partial(const void *x, const uint8_t *packed, const 
 extern "C" int fp4_hip_gemm_small(const void *x, const uint8_t *packed, const float *absmax, const void *bias, void *out,
                                   int64_t B, int64_t M, int64_t K, int blocksize, int dtype, void *stream) {
     using namespace fp4;
-    if (B < 1 || B > 16 || M < 0 || K <= 0) {
-        set_error("fp4_hip_gemm_small: B=%lld M=%lld K=%lld (need 1 <= B <= 16)", (long long)B, (long long)M, (long long)K);
+    if (B < 1 || B > 64 || M < 0 || K <= 0) {
+        set_error("fp4_hip_gemm_small: B=%lld M=%lld K=%lld (need 1 <= B <= 64)", (long long)B, (long long)M, (long long)K);
         return FP4_ERR_INVALID_ARGUMENT;
+    }
+    if (B > 16) {
+        // one launch covers 16 activation rows (the matrix-core tile); more rows are evenly split over several launches,
+        // each streaming the weight once - still ahead of dequant + GEMM while launches x 9.45 MB < the 76 MB the
+        // dequantised weight costs to write and read back
+        if (dtype != FP4_DTYPE_F16 && dtype != FP4_DTYPE_BF16) {
+            set_error("fp4_hip_gemm_small: more than 16 rows need a 16-bit dtype, got %d", dtype);
+            return FP4_ERR_UNSUPPORTED;
+        }
+        const int64_t chunks = (B + 15) / 16, per = (B + chunks - 1) / chunks;
+        for (int64_t b0 = 0; b0 < B; b0 += per) {
+            const int64_t nb = B - b0 < per ? B - b0 : per;
+            const int rc = fp4_hip_gemm_small(static_cast<const uint8_t *>(x) + size_t(b0) * size_t(K) * 2, packed, absmax, bias,
+                                              out ? static_cast<uint8_t *>(out) + size_t(b0) * size_t(M) * 2 : nullptr, nb, M, K,
+                                              blocksize, dtype, stream);
+            if (rc != FP4_OK) return rc;
+        }
+        return FP4_OK;
     }
     if (M == 0) return FP4_OK;
     if (!x || !packed || !absmax || !out) {

@@ -191,7 +191,7 @@ torch::Tensor gemm_small_fp4(torch::Tensor A, torch::Tensor B, torch::Tensor abs
     const int64_t m = Bshape[0], k = Bshape[1];
     TORCH_CHECK(A.dim() >= 1 && A.size(-1) == k, "gemm_small_fp4: last dim of the activation must be in_features = ", k);
     const int64_t rows = A.numel() / k;
-    TORCH_CHECK(rows >= 1 && rows <= 16, "gemm_small_fp4 covers 1..16 activation rows, got ", rows);
+    TORCH_CHECK(rows >= 1 && rows <= 64, "gemm_small_fp4 covers 1..64 activation rows, got ", rows);
     TORCH_CHECK(B.dtype() == torch::kUInt8 && B.numel() * 2 >= m * k, "B too small for a ", m, "x", k, " weight");
     TORCH_CHECK(absmax.scalar_type() == torch::kFloat32 && absmax.numel() * int64_t(blocksize) >= m * k, "absmax too small");
     const int dt = to_fp4_dtype(A.scalar_type(), "gemm_small_fp4");

@@ -14,7 +14,7 @@ everything else (batch or seq > 1)    ``qlinear`` = dequant + F.linear   (:616-6
 ====================================  =========================================
 
 Opt-in extensions (off by default so the table above holds): ``fuse_bias`` folds the post-GEMV bias add into the
-kernel epilogue (bit-identical); ``small_batch_fused`` sends 2..16 activation rows to the fused small-batch kernels.
+kernel epilogue (bit-identical); ``small_batch_fused`` sends 2..32 activation rows to the fused small-batch kernels.
 """
 from __future__ import annotations
 
@@ -49,7 +49,7 @@ class QuantData:
         self.numel = prod(shape)
         # fuse the post-GEMV `out += bias` into the kernel epilogue (bit-identical, one launch fewer)
         self.fuse_bias = fuse_bias
-        # opt-in: 2..16 activation rows go to the fused small-batch kernels instead of dequant + GEMM (the reference
+        # opt-in: 2..32 activation rows go to the fused small-batch kernels instead of dequant + GEMM (the reference
         # always dequantises for batch > 1, :616-617; same result up to rounding, ~5x less HBM traffic)
         self.small_batch_fused = small_batch_fused
         # per-call constants of the decode path, built once (224 calls per token in a 7B model)
@@ -132,7 +132,7 @@ class QuantData:
             return self.forward(A)
         # everything that is not a 2-D / 3-D single token with K % blocksize == 0 (:593-594, :614-617)
         rows = total // K
-        if (self.small_batch_fused and 2 <= rows <= 16 and A.dtype in (torch.float16, torch.bfloat16)
+        if (self.small_batch_fused and 2 <= rows <= 32 and A.dtype in (torch.float16, torch.bfloat16)
                 and ((self.blocksize == 64 and K % 512 == 0) or (rows <= 8 and K % self.blocksize == 0 and K % 32 == 0 and K <= 4096))):
             return ext.gemm_small_fp4(A.contiguous(), self.A.t(), self.absmax, self.blocksize, self._shape_list, self.bias)
         return self.qlinear(A)
