@@ -83,7 +83,7 @@ def test_4096x4096_every_variant(dtype, variant):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("M,K", [(14336, 4096), (4096, 14336), (1024, 4096), (2048, 768), (64, 2048), (66, 768), (5, 64), (1, 32),
-                                 (3, 8192), (257, 2112)])
+                                 (3, 8192), (257, 2112), (130, 11008), (70, 13824)])
 def test_model_shapes(dtype, M, K):
     packed, am, x = make_case(M, K, seed=M + K)
     x_t = torch_values(x, dtype)
@@ -94,7 +94,7 @@ def test_model_shapes(dtype, M, K):
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("iters", [1, 2, 4, 8])
 @pytest.mark.parametrize("M,K", [(14336, 4096), (4096, 14336), (1024, 4096), (2048, 768), (64, 2048), (66, 768), (5, 64), (1, 32),
-                                 (3, 8192), (257, 2112), (100, 16384), (7, 32768), (33, 1024), (19, 2048)])
+                                 (3, 8192), (257, 2112), (100, 16384), (7, 32768), (33, 1024), (19, 2048), (130, 11008), (9, 12288)])
 def test_register_x_geometry_all_band_splits(dtype, iters, M, K):
     """The second GEMV geometry (x in registers, K split across waves): every KSPLIT x G instantiation,
     ragged M, idle lanes, and the K > 16384 fall-back to the LDS geometry."""

@@ -1403,10 +1403,11 @@ int dispatch_regx(int iters, int ks_override, const void *x, const uint8_t *W, c
     int ks = C <= 32 ? 1 : (C <= 64 ? 2 : 4);
     if (ks_override == 1 || ks_override == 2 || ks_override == 4) ks = ks_override;
     const int need = (C + 32 * ks - 1) / (32 * ks);
-    const int g = need <= 1 ? 1 : (need <= 2 ? 2 : (need <= 4 ? 4 : 0));
+    // (a 3-deep slice only with the 4-way split: K = 11008, the Llama-2 down-projection, would waste a third of a 4-deep one)
+    const int g = need <= 1 ? 1 : (need <= 2 ? 2 : ((need == 3 && ks == 4) ? 3 : (need <= 4 ? 4 : 0)));
     if (g == 0) return -1;  // the x slice no longer fits the register budget; use the LDS geometry
     if (g == 2 && iters > 4) iters = 4;
-    if (g == 4 && iters > 2) iters = 2;
+    if (g >= 3 && iters > 2) iters = 2;
 #define FP4_RX(KS, GG, IT) return launch_regx<DT, KS, GG, IT>(x, W, absmax, bias, out, M, K, bs_shift, out_f32, stream)
 #define FP4_RX_IT(KS, GG)              \
     if (ks == KS && g == GG) {         \
@@ -1419,7 +1420,7 @@ int dispatch_regx(int iters, int ks_override, const void *x, const uint8_t *W, c
         }                              \
     }
     FP4_RX_IT(1, 1) FP4_RX_IT(1, 2) FP4_RX_IT(1, 4) FP4_RX_IT(2, 1) FP4_RX_IT(2, 2) FP4_RX_IT(2, 4) FP4_RX_IT(4, 1) FP4_RX_IT(4, 2)
-    FP4_RX_IT(4, 4)
+    FP4_RX_IT(4, 3) FP4_RX_IT(4, 4)
 #undef FP4_RX_IT
 #undef FP4_RX
     set_error("fp4_hip_gemv: unknown regx geometry (iters %d, ksplit %d, g %d)", iters, ks, g);
