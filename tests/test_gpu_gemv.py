@@ -83,7 +83,7 @@ def test_4096x4096_every_variant(dtype, variant):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("M,K", [(14336, 4096), (4096, 14336), (1024, 4096), (2048, 768), (64, 2048), (66, 768), (5, 64), (1, 32),
-                                 (3, 8192), (257, 2112), (130, 11008), (70, 13824)])
+                                 (3, 8192), (257, 2112), (130, 11008), (70, 13824), (130, 7168), (37, 28672)])
 def test_model_shapes(dtype, M, K):
     packed, am, x = make_case(M, K, seed=M + K)
     x_t = torch_values(x, dtype)
@@ -95,13 +95,28 @@ def test_model_shapes(dtype, M, K):
 @pytest.mark.parametrize("iters", [1, 2, 4, 8])
 @pytest.mark.parametrize("M,K", [(14336, 4096), (4096, 14336), (1024, 4096), (2048, 768), (64, 2048), (66, 768), (5, 64), (1, 32),
                                  (3, 8192), (257, 2112), (100, 16384), (7, 32768), (33, 1024), (19, 2048), (130, 11008), (9, 12288)])
-def test_register_x_geometry_all_band_splits(dtype, iters, M, K):
+def test_register_x_geometry_all_band_splits(dtype, iters, M, K):  # noqa: D401
     """The second GEMV geometry (x in registers, K split across waves): every KSPLIT x G instantiation,
     ragged M, idle lanes, and the K > 16384 fall-back to the LDS geometry."""
     packed, am, x = make_case(M, K, seed=M * 7 + K)
     x_t = torch_values(x, dtype)
     hipabi.set_variant("gemv", (1 << 24) | iters)
     y = hipabi.gemv(x_t, to_dev(packed), to_dev(am), M, K, 64)
+    check(y, x_t, packed, am, M, K, 64, dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("iters", [1, 2, 4])
+@pytest.mark.parametrize("M,K", [(4096, 14336), (66, 7168), (130, 14336), (37, 28672), (5, 7168)])
+def test_register_x_seven_band_geometry(dtype, iters, M, K):
+    """K = 7 * 1024 * {1, 2, 4}: seven waves, seven bands, 1 / 2 / 4 groups per lane, ragged M."""
+    packed, am, x = make_case(M, K, seed=M * 11 + K)
+    x_t = torch_values(x, dtype)
+    try:
+        hipabi.set_variant("gemv", (1 << 24) | (7 << 8) | iters)
+        y = hipabi.gemv(x_t, to_dev(packed), to_dev(am), M, K, 64)
+    finally:
+        hipabi.set_variant("gemv", -1)
     check(y, x_t, packed, am, M, K, 64, dtype)
 
 

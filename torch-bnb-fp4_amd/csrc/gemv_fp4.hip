@@ -1384,6 +1384,27 @@ int dispatch_regx(int iters, int ks_override, const void *x, const uint8_t *W, c
         if (iters == 2) return launch_regx<DT, 4, 1, 2, 8>(x, W, absmax, bias, out, M, K, bs_shift, out_f32, stream);
         if (iters == 4) return launch_regx<DT, 4, 1, 4, 8>(x, W, absmax, bias, out, M, K, bs_shift, out_f32, stream);
     }
+    // K = 7 * 1024 * {1, 2, 4} (7168, 14336, 28672 - the Llama-3 / Mistral intermediate sizes): seven waves split the row into
+    // seven bands, so no lane of a 32-chunk band is idle (4 bands leave an eighth of the deepest slice dead at 14336) and
+    // 28672 still fits the register-resident x slice
+    if (ks_override == 7 && C % 224 == 0 && (C / 224 == 1 || C / 224 == 2 || C / 224 == 4)) {
+        const int g7 = C / 224;
+        if (g7 == 4 && iters > 2) iters = 2;
+        if (iters > 4) iters = 4;
+#define FP4_RX7(GG)                                                                                                   \
+    switch (iters) {                                                                                                  \
+        case 1: return launch_regx<DT, 7, GG, 1, 7>(x, W, absmax, bias, out, M, K, bs_shift, out_f32, stream);        \
+        case 2: return launch_regx<DT, 7, GG, 2, 7>(x, W, absmax, bias, out, M, K, bs_shift, out_f32, stream);        \
+        default: return launch_regx<DT, 7, GG, 4, 7>(x, W, absmax, bias, out, M, K, bs_shift, out_f32, stream);       \
+    }
+        if (g7 == 1) { FP4_RX7(1) }
+        if (g7 == 2) { FP4_RX7(2) }
+        switch (iters) {
+            case 1: return launch_regx<DT, 7, 4, 1, 7>(x, W, absmax, bias, out, M, K, bs_shift, out_f32, stream);
+            default: return launch_regx<DT, 7, 4, 2, 7>(x, W, absmax, bias, out, M, K, bs_shift, out_f32, stream);
+        }
+#undef FP4_RX7
+    }
     if (ks_override == 8 && C > 128) {  // sweep hook: K split 8 ways over 8 waves (long rows)
         const int need8 = (C + 255) / 256;
         if (need8 <= 1) {
@@ -1432,6 +1453,11 @@ int default_variant16(int M, int K) {
     // rows per workgroup grow with M so that the grid stays at >= ~1024 workgroups (one resident round at
     // 4096 rows, ~2 at 14336).  K > 16384 falls back to the LDS geometry inside dispatch.
     const int C = K >> 5;
+    // seven bands (dispatch_regx): measured ahead of the 4-band / LDS geometries at 4096 x 7168 (5.3 vs 6.1 us), 4096 x 14336
+    // (8.6 vs 8.9) and 8192 x 28672 (30.7 vs 31.8), behind at 5120 x 14336 (profiles/r01_f_gemv_seven_bands.txt)
+    if (C == 224) return kRegxFlag | (7 << 8) | 2;
+    if (C == 448 && M <= 4096) return kRegxFlag | (7 << 8) | 4;
+    if (C == 896) return kRegxFlag | (7 << 8) | 2;
     const int ksplit = C <= 32 ? 1 : (C <= 64 ? 2 : 4);
     const int rows_per_iter = 2 * (4 / ksplit);
     const int max_iters = C <= 128 ? 4 : (C <= 256 ? 4 : 2);
