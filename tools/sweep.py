@@ -90,7 +90,7 @@ if what == "regx":
         x = torch.randn(K, device=dev).to(dt)
         nbytes = n // 2 + 4 * (n // 64) + (K + M) * isz
         res = []
-        for ks in (0, 7, 8):
+        for ks in (0, 5, 6, 7, 8):
             for it in (1, 2, 4, 8):
                 hipabi.set_variant("gemv", (1 << 24) | (ks << 8) | it)
                 try:

@@ -1405,6 +1405,22 @@ int dispatch_regx(int iters, int ks_override, const void *x, const uint8_t *W, c
         }
 #undef FP4_RX7
     }
+    // five / six bands for rows of exactly 5 or 6 (x 1, 2) band widths: K = 5120 / 10240 (Llama-2-13B hidden size) and 6144 / 12288
+    if ((ks_override == 5 && C % 160 == 0 && C / 160 <= 2) || (ks_override == 6 && C % 192 == 0 && C / 192 <= 2)) {
+        const int gg = C / (32 * ks_override);
+        if (iters > 4) iters = 4;
+#define FP4_RXN(KS, GG)                                                                                               \
+    switch (iters) {                                                                                                  \
+        case 1: return launch_regx<DT, KS, GG, 1, KS>(x, W, absmax, bias, out, M, K, bs_shift, out_f32, stream);      \
+        case 2: return launch_regx<DT, KS, GG, 2, KS>(x, W, absmax, bias, out, M, K, bs_shift, out_f32, stream);      \
+        default: return launch_regx<DT, KS, GG, 4, KS>(x, W, absmax, bias, out, M, K, bs_shift, out_f32, stream);     \
+    }
+        if (ks_override == 5 && gg == 1) { FP4_RXN(5, 1) }
+        if (ks_override == 5 && gg == 2) { FP4_RXN(5, 2) }
+        if (ks_override == 6 && gg == 1) { FP4_RXN(6, 1) }
+        if (ks_override == 6 && gg == 2) { FP4_RXN(6, 2) }
+#undef FP4_RXN
+    }
     if (ks_override == 8 && C > 128) {  // sweep hook: K split 8 ways over 8 waves (long rows)
         const int need8 = (C + 255) / 256;
         if (need8 <= 1) {
@@ -1455,6 +1471,13 @@ int default_variant16(int M, int K) {
     const int C = K >> 5;
     // seven bands (dispatch_regx): measured ahead of the 4-band / LDS geometries at 4096 x 7168 (5.3 vs 6.1 us), 4096 x 14336
     // (8.6 vs 8.9) and 8192 x 28672 (30.7 vs 31.8), behind at 5120 x 14336 (profiles/r01_f_gemv_seven_bands.txt)
+    // five / six bands where the row is exactly that many band widths (x 1 or 2): K = 5120 (5.1 vs 6.6 us at 5120 x 5120,
+    // 9.5 vs 12.0 at 13824 x 5120), 10240, 6144 (6.4 vs 7.5 at 6144 x 6144) - profiles/r01_f_gemv_five_six_bands.txt
+    if (C == 160 || C == 320 || C == 192) {
+        int it = 1;
+        while (it * 2 <= 4 && M / (2 * it * 2) >= 1024) it *= 2;
+        return kRegxFlag | ((C == 192 ? 6 : 5) << 8) | it;
+    }
     if (C == 224) return kRegxFlag | (7 << 8) | 2;
     if (C == 448 && M <= 4096) return kRegxFlag | (7 << 8) | 4;
     if (C == 896) return kRegxFlag | (7 << 8) | 2;
