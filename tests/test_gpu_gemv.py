@@ -83,7 +83,7 @@ def test_4096x4096_every_variant(dtype, variant):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("M,K", [(14336, 4096), (4096, 14336), (1024, 4096), (2048, 768), (64, 2048), (66, 768), (5, 64), (1, 32),
-                                 (3, 8192), (257, 2112), (130, 11008), (70, 13824), (130, 7168), (37, 28672), (5120, 5120), (70, 10240), (133, 6144)])
+                                 (3, 8192), (257, 2112), (130, 11008), (70, 13824), (130, 7168), (37, 28672), (5120, 5120), (70, 10240), (133, 6144), (4099, 8192)])
 def test_model_shapes(dtype, M, K):
     packed, am, x = make_case(M, K, seed=M + K)
     x_t = torch_values(x, dtype)
@@ -108,9 +108,10 @@ def test_register_x_geometry_all_band_splits(dtype, iters, M, K):  # noqa: D401
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("iters", [1, 2, 4])
 @pytest.mark.parametrize("M,K,bands", [(4096, 14336, 7), (66, 7168, 7), (130, 14336, 7), (37, 28672, 7), (5, 7168, 7), (66, 5120, 5),
-                                       (131, 10240, 5), (2048, 5120, 5), (66, 6144, 6), (35, 12288, 6)])
+                                       (131, 10240, 5), (2048, 5120, 5), (66, 6144, 6), (35, 12288, 6), (4100, 8192, 8), (66, 8192, 8),
+                                       (40, 16384, 8), (9, 32768, 8)])
 def test_register_x_five_six_seven_band_geometries(dtype, iters, M, K, bands):
-    """K = 5 / 6 / 7 band widths x {1, 2, 4}: as many waves as bands, 1 / 2 / 4 groups per lane, ragged M."""
+    """K = 5 / 6 / 7 / 8 band widths x {1, 2, 4}: as many waves as bands, 1 / 2 / 4 groups per lane, ragged M."""
     packed, am, x = make_case(M, K, seed=M * 11 + K)
     x_t = torch_values(x, dtype)
     try:
