@@ -928,12 +928,22 @@ __global__ __launch_bounds__(512) void gemm16_mfma_kernel(const uint16_t *__rest
     f32x4 acc[ROWT];
 #pragma unroll
     for (int rt = 0; rt < ROWT; ++rt) acc[rt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    for (int p = 0; p < passes; ++p) {
-        const int b0 = (p * 8 + wave) * NBW;
-        // x first (L2), then the weight stream (HBM), then the scales; all branch-free
-        u32x4 xr[XS ? 1 : NBW][2];
-        constexpr int kXUnits = XS ? XS * NBW / 8 : 1;  // 16-byte units of the x image per lane
-        u32x4 xstage[kXUnits];
+    // With up to 4 blocks per wave and pass (K = 14336 and the like: many short passes) the staged operands - weights, their
+    // scales, for XS > 0 the x slice - are loaded one pass AHEAD: the registers of pass p + 1 are requested as soon as pass p's
+    // have been written to the LDS images and fly while pass p is decoded and multiplied.  With 8 blocks per pass the extra live
+    // registers would cost the second workgroup per CU (128 -> 140..164 VGPRs), so there each pass loads its own.
+    constexpr bool kPassAhead = STAGE && NBW <= 4;
+    constexpr int kXUnits = XS ? XS * NBW / 8 : 1;  // 16-byte units of the x image per lane
+    constexpr int kLanesPerRow = 2 * NBW, kRowsPerInstr = 64 / kLanesPerRow, kInstr = (16 + kRowsPerInstr - 1) / kRowsPerInstr;
+    // 16 rows x NBW scales over 64 lanes (with NBW < 4 the upper lanes repeat rows: same address, same value)
+    constexpr int kScalesPerLane = NBW > 4 ? NBW / 4 : 1;
+    constexpr int kLanesPerScaleRow = NBW / kScalesPerLane;
+    const int srow = (lane / kLanesPerScaleRow) & 15, sj0 = (lane % kLanesPerScaleRow) * kScalesPerLane;
+    u32x4 xstage[kXUnits];
+    u32x4 wstage[ROWT][kInstr];
+    float amstage[ROWT][kScalesPerLane];
+    auto issue_staged = [&](int pass) {  // x first (L2), then the weight stream (HBM), then the scales; all branch-free
+        const int b0 = (pass * 8 + wave) * NBW;
         if constexpr (XS > 0) {
 #pragma unroll
             for (int i = 0; i < kXUnits; ++i) {
@@ -941,7 +951,30 @@ __global__ __launch_bounds__(512) void gemm16_mfma_kernel(const uint16_t *__rest
                 const int64_t nn = n < B ? n : B - 1;
                 xstage[i] = x4[((nn * K + 64 * b0) >> 3) + c16];
             }
-        } else {
+        }
+#pragma unroll
+        for (int rt = 0; rt < ROWT; ++rt)
+#pragma unroll
+            for (int i = 0; i < kInstr; ++i) {
+                const int rr = i * kRowsPerInstr + lane / kLanesPerRow;  // row of the tile this lane fetches
+                const int64_t row = row0 + 16 * rt + (rr & 15) < M ? row0 + 16 * rt + (rr & 15) : M - 1;
+                wstage[rt][i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(W) + ((row * K) >> 5) + 2 * b0 +
+                                                           (lane % kLanesPerRow));
+            }
+#pragma unroll
+        for (int rt = 0; rt < ROWT; ++rt) {
+            const int64_t row = row0 + 16 * rt + srow < M ? row0 + 16 * rt + srow : M - 1;
+            const float *src = absmax + row * nblk + b0 + sj0;
+#pragma unroll
+            for (int i = 0; i < kScalesPerLane; ++i) amstage[rt][i] = src[i];
+        }
+    };
+    if constexpr (kPassAhead) issue_staged(0);
+    for (int p = 0; p < passes; ++p) {
+        const int b0 = (p * 8 + wave) * NBW;
+        if constexpr (STAGE && !kPassAhead) issue_staged(p);
+        u32x4 xr[XS ? 1 : NBW][2];
+        if constexpr (XS == 0) {
 #pragma unroll
             for (int j = 0; j < NBW; ++j) {
                 const int64_t e = n_b * K + 64 * (b0 + j) + 16 * kb;
@@ -950,40 +983,13 @@ __global__ __launch_bounds__(512) void gemm16_mfma_kernel(const uint16_t *__rest
             }
         }
         u32x2 wq[ROWT][NBW];
-        constexpr int kLanesPerRow = 2 * NBW, kRowsPerInstr = 64 / kLanesPerRow, kInstr = (16 + kRowsPerInstr - 1) / kRowsPerInstr;
-        u32x4 wstage[ROWT][kInstr];
-        if constexpr (STAGE) {
-#pragma unroll
-            for (int rt = 0; rt < ROWT; ++rt)
-#pragma unroll
-                for (int i = 0; i < kInstr; ++i) {
-                    const int rr = i * kRowsPerInstr + lane / kLanesPerRow;  // row of the tile this lane fetches
-                    const int64_t row = row0 + 16 * rt + (rr & 15) < M ? row0 + 16 * rt + (rr & 15) : M - 1;
-                    wstage[rt][i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(W) + ((row * K) >> 5) + 2 * b0 +
-                                                               (lane % kLanesPerRow));
-                }
-        } else {
+        float am[ROWT][4][NBW];
+        if constexpr (!STAGE) {
 #pragma unroll
             for (int rt = 0; rt < ROWT; ++rt)
 #pragma unroll
                 for (int j = 0; j < NBW; ++j)
                     wq[rt][j] = __builtin_nontemporal_load(W2 + ((row_a[rt] * K) >> 4) + 4 * (b0 + j) + kb);
-        }
-        float am[ROWT][4][NBW];
-        // 16 rows x NBW scales over 64 lanes (with NBW < 4 the upper lanes repeat rows: same address, same value)
-        constexpr int kScalesPerLane = NBW > 4 ? NBW / 4 : 1;
-        constexpr int kLanesPerScaleRow = NBW / kScalesPerLane;
-        const int srow = (lane / kLanesPerScaleRow) & 15, sj0 = (lane % kLanesPerScaleRow) * kScalesPerLane;
-        float amstage[ROWT][kScalesPerLane];
-        if constexpr (STAGE) {
-#pragma unroll
-            for (int rt = 0; rt < ROWT; ++rt) {
-                const int64_t row = row0 + 16 * rt + srow < M ? row0 + 16 * rt + srow : M - 1;
-                const float *src = absmax + row * nblk + b0 + sj0;
-#pragma unroll
-                for (int i = 0; i < kScalesPerLane; ++i) amstage[rt][i] = src[i];
-            }
-        } else {
 #pragma unroll
             for (int rt = 0; rt < ROWT; ++rt) {
 #pragma unroll
@@ -1027,6 +1033,8 @@ __global__ __launch_bounds__(512) void gemm16_mfma_kernel(const uint16_t *__rest
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if constexpr (kPassAhead)
+                if (p + 1 < passes) issue_staged(p + 1);  // uniform
 #pragma unroll
             for (int rt = 0; rt < ROWT; ++rt) {
                 const uint8_t *img = s_w + (wave * ROWT + rt) * 16 * kStageStride;
