@@ -212,7 +212,7 @@ def test_partial_f32_output_and_k_split_sum(dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("kernel", [0, 1 | (1 << 4), 1 | (2 << 4), 1 | (1 << 4) | (1 << 8), 1 | (2 << 4) | (1 << 8)])  # VALU kernel; matrix-core kernel: 1 / 2 row tiles, LDS-staged / direct weight loads
+@pytest.mark.parametrize("kernel", [0, 1 | (1 << 4), 1 | (2 << 4), 1 | (1 << 4) | (1 << 8), 1 | (2 << 4) | (1 << 8), 1 | (1 << 4) | (2 << 14)])  # VALU kernel; matrix-core kernel: 1 / 2 row tiles, LDS-staged / direct weight loads, 8 blocks per pass wherever they divide K
 @pytest.mark.parametrize("B", [1, 2, 3, 4, 5, 8, 9, 13, 16])
 @pytest.mark.parametrize("M,K", [(4096, 4096), (1024, 4096), (2048, 768), (66, 2048), (257, 1024), (300, 8192), (40, 14336), (33, 512)])
 def test_small_batch_fused_gemm(dtype, kernel, B, M, K):

@@ -1252,6 +1252,7 @@ int g_mfma_rowt = -1;   // sweeps: force 1 or 2 row tiles per workgroup
 int g_mfma_stage = -1;  // sweeps: 0 = direct 8-byte weight loads, otherwise LDS-staged 16-byte loads
 int g_mfma_xstage = -1;  // sweeps: 0 = B fragments straight from global even for batch <= 8
 int g_mfma_persist = -1;  // sweeps: 0 = never the persistent kernel, 1 = whenever it applies (K = 4096, batch <= 4)
+int g_mfma_nbw4 = -1;     // sweeps: 1 = at most 4 blocks per wave and pass (pass-ahead loads), 0 = 8 wherever they divide K
 
 template <int DT>
 int dispatch_mfma(const void *x, const uint8_t *W, const float *absmax, const void *bias, void *out, int B, int M, int K,
@@ -1319,7 +1320,9 @@ int dispatch_mfma(const void *x, const uint8_t *W, const float *absmax, const vo
     } else {                    \
         FP4_MF(NBW, 1);         \
     }
-    if (units % 8 == 0) { FP4_MF_RT(8) }
+    // 8 blocks per wave and pass only where that is the whole K (one pass); with several passes 4 blocks + the pass-ahead loads
+    // win (8192 x 8192 x 4 rows: 12.4 -> 10.6 us, 28672 x 8192: 36 -> 33 us; profiles/r01_f_small_batch_pass_ahead.txt)
+    if (units % 8 == 0 && (g_mfma_nbw4 == 0 || (g_mfma_nbw4 < 0 && units == 8))) { FP4_MF_RT(8) }
     if (units % 4 == 0) { FP4_MF_RT(4) }
     if (units % 2 == 0) { FP4_MF_RT(2) }
     FP4_MF_RT(1)
@@ -1522,6 +1525,7 @@ void set_small_variant(int v) {
     g_mfma_stage = v < 0 ? -1 : ((v >> 8) & 1 ? 0 : 1);  // bit 8: direct (unstaged) weight loads
     g_mfma_xstage = v < 0 ? -1 : ((v >> 9) & 1 ? 0 : 1);  // bit 9: B fragments straight from global
     g_mfma_persist = v < 0 ? -1 : ((v >> 10) & 3) == 1 ? 0 : (((v >> 10) & 3) == 2 ? 1 : -1);  // bits 10-11: 1 = off, 2 = force
+    g_mfma_nbw4 = v < 0 ? -1 : ((v >> 14) & 3) == 1 ? 1 : (((v >> 14) & 3) == 2 ? 0 : -1);  // bits 14-15: 1 = 4 blocks per pass, 2 = 8
 }
 
 }  // namespace fp4
