@@ -21,11 +21,14 @@
 //
 // Kernels, in file order
 //  * gemv16_kernel        - LDS geometry (the north-star mapping): one wave64 per row, x staged once per workgroup in a
-//                           pre-permuted, bank-conflict-free LDS image; serves K > 16384 and stays selectable for sweeps.
+//                           pre-permuted, bank-conflict-free LDS image; serves K > 16384 (other than 28672) and stays selectable for sweeps.
 //  * gemv16_regx_kernel   - register-x geometry, the DEFAULT for 16-bit activations: a lane owns the same K-chunks for every
-//                           row of its workgroup, so its slice of x lives in VGPRs; K split across the 4 waves.
-//  * gemm16_small_kernel  - the same with 2..8 activation rows (fp4_hip_gemm_small).
+//                           row of its workgroup, so its slice of x lives in VGPRs; K split into 1..8 bands of 32 chunks,
+//                           one wave per band, the band count chosen so that no lane of a band idles (default_variant16).
+//  * gemm16_small_kernel  - the same with 2..8 activation rows on the VALU (fallback of fp4_hip_gemm_small).
 //  * gemv32_kernel / gemv32_regx_kernel - f32 activations (bit-faithful CODE_PARAM f32 table in LDS).
+//  * gemm16_mfma_kernel / gemm16_mfma_persist_kernel - 2..16 activation rows on the matrix cores (fp4_hip_gemm_small):
+//                           one-shot for any K % 512 == 0, persistent with pass-independent B fragments for K = 4096.
 //  * gemv_generic_kernel  - any even K / blocksize, unaligned operands.
 #include "fp4_common.h"
 
@@ -1478,7 +1481,7 @@ int dispatch_regx(int iters, int ks_override, const void *x, const uint8_t *W, c
 int default_variant16(int M, int K) {
     // Measured on MI355X (profiles/r01_*): the register-x geometry wins at every decode shape it covers;
     // rows per workgroup grow with M so that the grid stays at >= ~1024 workgroups (one resident round at
-    // 4096 rows, ~2 at 14336).  K > 16384 falls back to the LDS geometry inside dispatch.
+    // 4096 rows, ~2 at 14336).  K > 16384 (other than 28672) falls back to the LDS geometry inside dispatch.
     const int C = K >> 5;
     // seven bands (dispatch_regx): measured ahead of the 4-band / LDS geometries at 4096 x 7168 (5.3 vs 6.1 us), 4096 x 14336
     // (8.6 vs 8.9) and 8192 x 28672 (30.7 vs 31.8), behind at 5120 x 14336 (profiles/r01_f_gemv_seven_bands.txt)
