@@ -41,6 +41,9 @@ def main():
     ap.add_argument("--tokens", type=int, default=64)
     ap.add_argument("--dtype", default="bfloat16")
     ap.add_argument("--fuse", action="store_true", help="one GEMV for q|k|v and one for gate|up (row concatenation)")
+    ap.add_argument("--batch", type=int, default=1, help="sequences decoded together (activation rows per Linear call)")
+    ap.add_argument("--reference-dispatch", action="store_true",
+                    help="batch > 1 through dequant + GEMM like the reference, instead of the fused small-batch kernels")
     args = ap.parse_args()
     cfg = dict(MODELS[args.model])
     if args.layers:
@@ -69,7 +72,8 @@ def main():
             packed, absmax = fp4_weight(m, k)
         if world == 1:
             state = pkg.QuantState(absmax, (m, k), pkg.ext.code_table("tree").to(dev), BS)
-            qd = pkg.QuantData(packed, state, state.shape, original_lin=None, bias=None)
+            qd = pkg.QuantData(packed, state, state.shape, original_lin=None, bias=None,
+                               small_batch_fused=not args.reference_dispatch)
             return qd.forward
         if kind == "col":
             return par.ColumnParallelFP4Linear(packed, absmax, (m, k), BS, gather_output=False)
@@ -82,7 +86,7 @@ def main():
         layers = [dict(q=linear(H, H, "col"), k=linear(KV, H, "col"), v=linear(KV, H, "col"), o=linear(H, H, "row"),
                        gate=linear(I, H, "col"), up=linear(I, H, "col"), down=linear(H, I, "row")) for _ in range(L)]
     lm_head = torch.nn.Linear(H, V, bias=False, device=dev, dtype=dtype)
-    h0 = torch.randn(1, H, device=dev, generator=gen).to(dtype)
+    h0 = torch.randn(args.batch, H, device=dev, generator=gen).to(dtype)
 
     def token(h):
         for ly in layers:
@@ -137,9 +141,10 @@ def main():
         best = graph_s or eager
         print(json.dumps({
             "model": args.model, "layers": L, "n_gpus": world, "dtype": args.dtype, "fp4_linear_calls_per_token": (4 if (args.fuse and world == 1) else 7) * L,
-            "fp4_bytes_per_token_per_gpu": per_token_fp4, "eager_ms_per_token": round(eager * 1e3, 3),
-            "graph_ms_per_token": None if graph_s is None else round(graph_s * 1e3, 3),
-            "tokens_per_s": round(1 / best, 1), "fp4_stream_gbps_per_gpu": round(per_token_fp4 / best / 1e9, 1),
+            "fp4_bytes_per_token_per_gpu": per_token_fp4, "eager_ms_per_step": round(eager * 1e3, 3),
+            "graph_ms_per_step": None if graph_s is None else round(graph_s * 1e3, 3),
+            "batch": args.batch, "batch_path": "reference dispatch (dequant + GEMM)" if args.reference_dispatch and args.batch > 1 else "fused",
+            "tokens_per_s": round(args.batch / best, 1), "fp4_stream_gbps_per_gpu": round(per_token_fp4 / best / 1e9, 1),
             "hbm_floor_ms_per_token_at_8TBps": round((per_token_fp4 + V * H * 2 // 1) / 8e12 * 1e3, 3),
             "data": "synthetic random FP4 bytes + scales; attention replaced by identity; lm_head dense " + args.dtype,
         }))
