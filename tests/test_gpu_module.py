@@ -235,3 +235,24 @@ def test_fuse_rows_is_bit_identical_to_separate_layers():
         assert (got.float() - ref.float()).abs().max().item() <= 2e-2 * (1 + ref.float().abs().max().item())
     with pytest.raises(ValueError):
         P.TorchFP4Linear.fuse([q, P.TorchFP4Linear(P.swap_linear_with_bnb_linear(nn.Linear(512, 64).to(dev())).to(dev()))])
+
+
+def test_set_small_batch_fused_switches_the_batch_path():
+    """Same model, same batched input: the fused small-batch kernels and the reference dispatch (dequant + GEMM) agree
+    to rounding, and the switch reaches every converted layer."""
+    import torch_bnb_fp4 as pkg
+
+    torch.manual_seed(3)
+    model = torch.nn.Sequential(torch.nn.Linear(512, 1024), torch.nn.SiLU(), torch.nn.Linear(1024, 512)).to(torch.bfloat16)
+    model = pkg.recursively_replace_with_fp4_linear(model, as_dtype=torch.bfloat16, device=dev())
+    x = torch.randn(6, 512, device=dev(), dtype=torch.bfloat16)
+    with torch.inference_mode():
+        ref = model(x)
+        assert pkg.set_small_batch_fused(model, True) == 2
+        assert all(m.quant_data.small_batch_fused for m in model.modules() if isinstance(m, pkg.TorchFP4Linear))
+        fused = model(x)
+        assert pkg.set_small_batch_fused(model, False) == 2
+        again = model(x)
+    assert torch.equal(again, ref)
+    assert torch.allclose(fused.float(), ref.float(), rtol=2e-2, atol=2e-2)
+

@@ -29,6 +29,7 @@ from .serialization import fp4_linear_from_bnb_state, fp4_linear_to_bnb_state, l
 from .surgery import (
     check_if_name_contained_in_list,
     recursively_replace_with_fp4_linear,
+    set_small_batch_fused,
     swap_linear_with_bnb_linear,
     todevice_if_necessary,
 )
@@ -56,5 +57,6 @@ __all__ = [
     "fp4_linear_from_bnb_state",
     "save_fp4_model",
     "load_fp4_layers",
+    "set_small_batch_fused",
 ]
 __version__ = "0.1.0"

@@ -127,3 +127,18 @@ def recursively_replace_with_fp4_linear(
         torch.cuda.empty_cache()  # the dense copies are gone; give their blocks back (:919-920)
     if return_final_module:
         return module
+
+
+def set_small_batch_fused(module: nn.Module, enabled: bool = True) -> int:
+    """Route 2..32 activation rows of every :class:`TorchFP4Linear` below ``module`` to the fused small-batch kernels
+    (``enabled=True``) or back to the reference's dispatch, dequant + GEMM for every batch > 1
+    (torch_bnb_fp4/__init__.py:592,616-617; the default, so that a converted model behaves like the reference's).
+    Not part of the reference surface.  Returns the number of layers touched.  Batched decode through Mistral-7B shapes:
+    3 237 tok/s fused vs 963 tok/s through the reference dispatch at 8 sequences (profiles/)."""
+    n = 0
+    for m in module.modules():
+        if isinstance(m, TorchFP4Linear):
+            m.quant_data.small_batch_fused = bool(enabled)
+            n += 1
+    return n
+
