@@ -9,7 +9,9 @@ HBM ("HBM-cold"); same-buffer "hot" figures are reported separately.  Launches a
 HIP graphs so the host never paces the GPU; the timed region still contains one kernel boundary
 per launch, exactly as a decode loop would.
 
-Contract: `python bench.py --gpus N --steps K --warmup W` (N > 1 under torchrun, one rank per GPU);
+Contract: `python bench.py --gpus N --steps K --warmup W`.  N > 1: one rank per GPU; either started under torchrun
+(WORLD_SIZE set) or plainly, in which case this script starts its own N workers as child processes
+(`python -m torch.distributed.run ...`, launch_workers below) BEFORE it touches the GPU and relays rank 0's line;
 W untimed warm-up steps, then exactly K timed steps between barrier + synchronize, MAX over ranks,
 rank 0 prints ONE JSON line.  `value` = whole-job dequant GB/s (algorithmic bytes, inputs resident
 in HBM); the GEMV figures, the HIP-event roofline of the dequant kernel and a pure-torch CPU
@@ -22,7 +24,9 @@ import argparse
 import ctypes
 import json
 import os
+import socket
 import statistics
+import subprocess
 import sys
 import time
 
@@ -119,6 +123,77 @@ def tp_ksplit_leg(lib, dist, backend, rank, world, dev, x, packed0, absmax0, bar
         barrier()
         out[name] = round((time.perf_counter() - t0) / 200 * 1e6, 2)
     out["note"] = f"K split {world} ways ({ks} columns per GPU), eager launches, backend {backend}; the collective is latency-bound"
+    return out
+
+
+def launch_workers(n, argv, script=None, timeout_s=None, out=None):
+    """`python bench.py --gpus N` without torchrun: start the N ranks as CHILD processes (never exec: a process that has
+    touched the GPU must not be replaced, and this parent stays GPU-free so that it can relay), wait for them, print
+    rank 0's JSON line on our stdout and return the children's exit code (non-zero if any rank failed: no retry)."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), script or os.path.abspath(__file__), *argv]
+    out = out or sys.stdout
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    try:
+        for raw in proc.stdout:  # rank 0 prints exactly one JSON line; anything else a child writes goes to stderr
+            txt = raw.strip()
+            if txt.startswith("{") and '"metric"' in txt:
+                line = txt
+            elif txt:
+                print(txt, file=sys.stderr, flush=True)
+        rc = proc.wait(timeout=timeout_s)
+    except BaseException:
+        proc.kill()
+        proc.wait()
+        raise
+    if line is not None:
+        print(line, file=out, flush=True)
+    if rc != 0:
+        print(f"bench.py: the {n}-rank worker group exited with code {rc}", file=sys.stderr, flush=True)
+        return rc
+    if line is None:
+        print("bench.py: the worker group printed no result line", file=sys.stderr, flush=True)
+        return 1
+    return 0
+
+
+def c5_leg(dist, backend, rank, world, dev, barrier, tokens=16):
+    """N > 1 only, outside the timed region: BASELINE config 5 - every FP4 Linear of a Llama-3-8B shaped decoder through
+    Column/RowParallelFP4Linear (q/k/v/gate/up M-split, o/down K-split + one f32 all-reduce each), batch-1 decode."""
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import decode_bench as db
+
+    cfg = dict(db.MODELS["llama3-8b"])
+    cfg["layers"] = int(os.environ.get("FP4_BENCH_C5_LAYERS", cfg["layers"]))
+    out = {"model": "llama3-8b shapes", "layers": cfg["layers"], "backend": backend}
+    # eager first (always valid); a HIP graph around a live RCCL communicator only on request (FP4_BENCH_C5_GRAPH=1),
+    # the one-shot peer-slot all-reduce (no RCCL call inside the step) is always captured
+    modes = [("dist", os.environ.get("FP4_BENCH_C5_GRAPH", "0") == "1" and backend == "nccl")]
+    if os.environ.get("FP4_BENCH_C5_ONESHOT", "1") == "1":
+        modes.append(("oneshot", True))
+    for ar, graph in modes:
+        try:
+            token, h0, meta = db.build_token_fn(cfg, dev, torch.bfloat16, world, rank, allreduce=ar, lm_head=False)
+            t = db.time_tokens(token, h0, tokens, graph=graph, barrier=barrier)
+            best = t["graph_s"] or t["eager_s"]
+            out[ar] = {"eager_ms_per_token": round(t["eager_s"] * 1e3, 3),
+                       "graph_ms_per_token": None if t["graph_s"] is None else round(t["graph_s"] * 1e3, 3),
+                       "graph_error": t["graph_error"],
+                       "fp4_gbps_per_gpu": round(meta["fp4_bytes_per_token_per_gpu"] / best / 1e9, 1)}
+            out["allreduces_per_token"] = meta["allreduces_per_token"]
+            out["fp4_bytes_per_token_per_gpu"] = meta["fp4_bytes_per_token_per_gpu"]
+            del token, h0
+        except Exception as exc:
+            out[ar] = {"error": repr(exc)[:300]}
+        torch.cuda.empty_cache()
+    out["note"] = ("2 all-reduces of 16 KiB f32 per layer; latency-bound; eager launches are host-bound; attention replaced by "
+                   "identity, lm_head left out")
     return out
 
 
@@ -228,11 +303,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        sys.exit(f"--gpus {args.gpus} needs torchrun with --nproc-per-node {args.gpus} (WORLD_SIZE={world})")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: nothing below this line has touched the GPU yet (importing torch does not)
+        sys.exit(launch_workers(args.gpus, sys.argv[1:]))
+    if args.gpus != world:
+        sys.exit(f"--gpus {args.gpus} does not match WORLD_SIZE={world}")
     # one rank per GPU; FP4_BENCH_BACKEND=gloo lets the N > 1 code path be rehearsed on a box with fewer GPUs
     backend = os.environ.get("FP4_BENCH_BACKEND", "nccl")
-    local_dev = local % max(1, torch.cuda.device_count())
+    ndev = torch.cuda.device_count()
+    if world > 1 and backend == "nccl" and ndev < world:
+        sys.exit(f"--gpus {world} needs {world} visible GPUs for the RCCL backend, found {ndev} "
+                 "(FP4_BENCH_BACKEND=gloo rehearses the N > 1 path with ranks sharing devices)")
+    local_dev = local % max(1, ndev)
     torch.cuda.set_device(local_dev)
     dev = torch.device("cuda", local_dev)
     if world > 1:
@@ -298,6 +380,11 @@ def main():
                 extra["tp_ksplit"] = tp_ksplit_leg(lib, dist, backend, rank, world, dev, x, packed[0], absmax[0], barrier)
             except Exception as exc:  # never let the optional leg take the headline line down
                 extra["tp_ksplit"] = {"error": repr(exc)[:300]}
+            if os.environ.get("FP4_BENCH_C5", "1") == "1":
+                try:
+                    extra["c5_llama3_8b_tp"] = c5_leg(dist, backend, rank, world, dev, barrier)
+                except Exception as exc:
+                    extra["c5_llama3_8b_tp"] = {"error": repr(exc)[:300]}
         if rank == 0:
             hot_dq = capture(lambda: [lib.dequant(packed[0], absmax[0], outs[0], n) for _ in range(32)])
             hot_gv = capture(lambda: [lib.gemv(x, packed[0], absmax[0], ys[0], M, K) for _ in range(128)])

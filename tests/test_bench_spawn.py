@@ -1,0 +1,60 @@
+"""`python bench.py --gpus N` without torchrun starts its own workers (bench.launch_workers): the spawn / relay / exit-code
+logic is exercised here on CPU with a stand-in worker script (gloo, two ranks); the real thing runs in test_gpu_bench.py."""
+import io
+import json
+import os
+import sys
+import textwrap
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+
+
+def _script(tmp_path, body):
+    p = tmp_path / "worker.py"
+    p.write_text(textwrap.dedent(body))
+    return str(p)
+
+
+def test_launch_workers_relays_rank0_line_and_exit_code(tmp_path, capfd):
+    import bench
+
+    ok = _script(tmp_path, """
+        import json, os, sys
+        import torch, torch.distributed as dist
+        assert os.environ["MASTER_ADDR"] == "127.0.0.1" and os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+        dist.init_process_group("gloo")
+        t = torch.tensor([float(dist.get_rank() + 1)])
+        dist.all_reduce(t)
+        print("chatter from rank", dist.get_rank())          # must not reach the parent's stdout
+        if dist.get_rank() == 0:
+            print(json.dumps({"metric": "stand-in", "n_gpus": dist.get_world_size(), "sum": t.item(), "argv": sys.argv[1:]}))
+        dist.barrier()
+        dist.destroy_process_group()
+    """)
+    out = io.StringIO()
+    rc = bench.launch_workers(2, ["--gpus", "2", "--steps", "3"], script=ok, timeout_s=300, out=out)
+    lines = [l for l in out.getvalue().splitlines() if l.strip()]
+    assert rc == 0 and len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["sum"] == 3.0 and rec["argv"] == ["--gpus", "2", "--steps", "3"]
+    assert "chatter" in capfd.readouterr().err
+
+    bad = _script(tmp_path, """
+        import os, sys
+        sys.exit(3 if os.environ["RANK"] == "1" else 0)
+    """)
+    out = io.StringIO()
+    assert bench.launch_workers(2, [], script=bad, timeout_s=300, out=out) != 0  # a failed rank is a failed run: no retry
+    assert out.getvalue() == ""
+
+    silent = _script(tmp_path, "pass\n")
+    assert bench.launch_workers(2, [], script=silent, timeout_s=300, out=io.StringIO()) == 1  # no result line is a failure
+
+
+def test_plain_invocation_with_gpus_gt_1_spawns_before_any_gpu_call():
+    """Source-level guard: in bench.main the spawn branch comes before the first torch.cuda call."""
+    src = open(os.path.join(REPO, "bench.py")).read()
+    main = src[src.index("def main():"):]
+    assert main.index("launch_workers(args.gpus") < main.index("torch.cuda.")
+    assert "os.exec" not in src

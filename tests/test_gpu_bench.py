@@ -1,0 +1,42 @@
+"""bench.py end to end on the GPU box: the N = 1 line's schema, and `python bench.py --gpus 2` WITHOUT torchrun (the script
+starts its own two workers; FP4_BENCH_BACKEND=gloo lets both ranks share the one GPU of the box, everything but the
+transport being the N > 1 production path, including the tensor-parallel C5 leg)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SCHEMA = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+          "dtype", "data", "config", "roofline"}
+
+
+def _run(args, env_extra):
+    env = dict(os.environ, **env_extra)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), *args], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_single_gpu_line_schema():
+    rec = _run(["--steps", "2", "--warmup", "1", "--matrices", "8", "--no-cpu"], {})
+    assert SCHEMA <= set(rec) and rec["n_gpus"] == 1 and rec["steps"] == 2 and rec["unit"] == "GB/s" and rec["dtype"] == "bf16"
+    r = rec["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert 0.2 < r["frac"] < 1.0 and "workload" in rec["config"] and "model" not in rec["config"]
+
+
+def test_two_ranks_self_launched_over_gloo():
+    rec = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--matrices", "8"],
+               {"FP4_BENCH_BACKEND": "gloo", "FP4_BENCH_C5_LAYERS": "2"})
+    assert SCHEMA <= set(rec) and rec["n_gpus"] == 2 and rec["scaling"] == "weak"
+    assert "error" not in rec["tp_ksplit"], rec["tp_ksplit"]
+    c5 = rec["c5_llama3_8b_tp"]
+    assert "error" not in c5 and c5["allreduces_per_token"] == 4 and "error" not in c5["dist"], c5

@@ -113,9 +113,12 @@ class RowParallelFP4Linear(nn.Module):
     """K-split: this rank owns ``in_features / world`` columns; outputs are summed across ranks in f32."""
 
     def __init__(self, packed, absmax, shape, blocksize: int = 64, bias: Optional[torch.Tensor] = None, group=None,
-                 input_is_parallel: bool = False):
+                 input_is_parallel: bool = False, allreduce: str = "dist"):
         super().__init__()
+        if allreduce not in ("dist", "oneshot"):
+            raise ValueError(f"allreduce must be 'dist' or 'oneshot', got {allreduce!r}")
         self.group = group
+        self.allreduce = allreduce
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         p, a, local = shard_cols(packed, absmax, shape, blocksize, self.rank, self.world)
         self.quant_data = _quant_data(p, a, local, blocksize, None)
