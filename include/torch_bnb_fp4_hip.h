@@ -4,11 +4,15 @@
  *
  * This is the drop-in boundary of the hot path: plain pointers and sizes, no torch
  * types.  Every pointer is a DEVICE pointer valid on the HIP device that is current
- * on the calling thread; `stream` is a hipStream_t (NULL = the null stream).  All
- * entry points are asynchronous (they enqueue on `stream` and return), stateless and
- * re-entrant.  Return value: 0 on success, otherwise an fp4_status code;
- * fp4_hip_last_error() then holds a thread-local message.  Nothing here allocates
- * or synchronises, so every call is HIP-graph capturable.
+ * on the calling thread; `stream` is a hipStream_t (NULL = the null stream).  The
+ * compute entry points are asynchronous (they enqueue on `stream` and return) and
+ * re-entrant: they keep no state between calls and may be called from any number of
+ * threads at once.  The only process-wide state is the benchmark hook
+ * fp4_hip_set_variant() (relaxed atomics, read once per launch; a production caller
+ * never touches it) and a per-device cache of the compute-unit count.
+ * Return value: 0 on success, otherwise an fp4_status code; fp4_hip_last_error() then
+ * holds a thread-local message.  The compute entry points neither allocate nor
+ * synchronise, so every one of them is HIP-graph capturable.
  *
  * Each entry point names the reference interface it replaces
  * (aredden/torch-bnb-fp4, paths relative to that checkout).  The reference has no
@@ -126,7 +130,8 @@ FP4_HIP_API int fp4_hip_quantize_blockwise(const void *w, int w_dtype, uint8_t *
  * Tuning hook for benchmarks/sweeps: selects a kernel geometry by name
  * ("dequant", "gemv", "gemm_small", "quantize" = workgroups per CU of the persistent
  * grid).  variant < 0 (quantize: 0) restores the built-in heuristic.
- * Process-wide; not part of the reference surface.
+ * Process-wide (relaxed atomics: safe to flip while other threads launch, each launch
+ * reads it once); for sweeps and tests only, not part of the reference surface.
  */
 FP4_HIP_API int fp4_hip_set_variant(const char *kernel, int variant);
 

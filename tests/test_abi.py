@@ -1,9 +1,11 @@
 """The C-ABI library loads and exports exactly what include/torch_bnb_fp4_hip.h declares; argument
 validation (which returns before any HIP call) behaves as documented.  No GPU needed."""
 import ctypes
+import os
 import subprocess
 
 import numpy as np
+import pytest
 
 import hipabi
 from oracle import fp4_oracle as o
@@ -49,3 +51,30 @@ def test_argument_validation_without_gpu():
     assert l.fp4_hip_quantize_blockwise(one, hipabi.F16, one, one, 64, 48, None) == hipabi.ERR_UNSUPPORTED
     assert l.fp4_hip_set_variant(b"nope", 1) == hipabi.ERR_INVALID
     assert l.fp4_hip_set_variant(b"gemv", -1) == hipabi.OK
+
+
+def test_build_refuses_kernels_that_spill():
+    """build.py parses hipcc's kernel-resource-usage remarks and fails the build on any spill / scratch use."""
+    import importlib.util
+    import json
+
+    PKG_ROOT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "torch-bnb-fp4_amd")
+    spec = importlib.util.spec_from_file_location("fp4_build", os.path.join(PKG_ROOT, "build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    remark = ("a.hip:1:1: remark: Function Name: k_good [-Rpass-analysis=kernel-resource-usage]\n"
+              "a.hip:1:1: remark:     VGPRs: 64 [-Rpass-analysis=kernel-resource-usage]\n"
+              "a.hip:1:1: remark:     ScratchSize [bytes/lane]: 0 [-Rpass-analysis=kernel-resource-usage]\n"
+              "a.hip:1:1: remark:     VGPRs Spill: 0 [-Rpass-analysis=kernel-resource-usage]\n"
+              "a.hip:9:1: remark: Function Name: k_bad [-Rpass-analysis=kernel-resource-usage]\n"
+              "a.hip:9:1: remark:     VGPRs: 128 [-Rpass-analysis=kernel-resource-usage]\n"
+              "a.hip:9:1: remark:     ScratchSize [bytes/lane]: 100 [-Rpass-analysis=kernel-resource-usage]\n"
+              "a.hip:9:1: remark:     VGPRs Spill: 25 [-Rpass-analysis=kernel-resource-usage]\n")
+    usage = mod.parse_resource_usage(remark)
+    assert usage == {"k_good": {"vgprs": 64, "scratch": 0, "vgpr_spill": 0}, "k_bad": {"vgprs": 128, "scratch": 100, "vgpr_spill": 25}}
+    mod.check_no_spills({"k_good": usage["k_good"]}, "a.hip")
+    with pytest.raises(RuntimeError, match="k_bad"):
+        mod.check_no_spills(usage, "a.hip")
+    # the library that was actually built: every shipped kernel is listed and none spills
+    shipped = json.load(open(os.path.join(PKG_ROOT, "torch_bnb_fp4", "lib", "kernel_resources.json")))
+    assert len(shipped) > 100 and all(not (v.get("vgpr_spill") or v.get("sgpr_spill") or v.get("scratch")) for v in shipped.values())

@@ -23,9 +23,10 @@ INCLUDE = os.path.join(REPO, "include")
 LIB_DIR = os.path.join(HERE, "torch_bnb_fp4", "lib")
 HIP_LIB = os.path.join(LIB_DIR, "libtorch_bnb_fp4_hip.so")
 EXT_LIB = os.path.join(HERE, "torch_bnb_fp4_ext.so")
+OBJ_DIR = os.path.join(REPO, "build_tmp", "obj")
 
-HIP_SOURCES = ["capi.hip", "dequant_fp4.hip", "gemv_fp4.hip", "quantize_fp4.hip"]
-HIP_HEADERS = ["fp4_common.h", os.path.join(INCLUDE, "torch_bnb_fp4_hip.h")]
+HIP_SOURCES = ["capi.hip", "dequant_fp4.hip", "gemv_fp4.hip", "gemm_small_fp4.hip", "quantize_fp4.hip"]
+HIP_HEADERS = ["fp4_common.h", "gemv_common.h", os.path.join(INCLUDE, "torch_bnb_fp4_hip.h")]
 ARCH = "gfx950"
 # Kernel arguments are preloaded into SGPRs at wave launch instead of being fetched with s_load at the top of the
 # kernel: for kernels this short that is measurable (4096x4096 bf16: GEMV 4.16 -> 3.91 us, dequant 7.44 -> 7.22 us).
@@ -50,14 +51,70 @@ def _run(cmd) -> None:
     subprocess.check_call(cmd)
 
 
+def parse_resource_usage(text: str):
+    """hipcc -Rpass-analysis=kernel-resource-usage remarks -> {kernel: {"vgprs", "sgprs", "scratch", "vgpr_spill", "sgpr_spill",
+    "occupancy", "lds"}} (the last record of a kernel wins: remarks repeat per offload pass)."""
+    import re
+
+    fields = {"VGPRs": "vgprs", "TotalSGPRs": "sgprs", "ScratchSize [bytes/lane]": "scratch", "VGPRs Spill": "vgpr_spill",
+              "SGPRs Spill": "sgpr_spill", "Occupancy [waves/SIMD]": "occupancy", "LDS Size [bytes/block]": "lds"}
+    out, cur = {}, None
+    for line in text.splitlines():
+        m = re.search(r"remark:\s+Function Name: (\S+)", line)
+        if m:
+            cur = out.setdefault(m.group(1), {})
+            continue
+        m = re.search(r"remark:\s+([A-Za-z \[\]/]+?): (\d+) \[-Rpass-analysis", line)
+        if m and cur is not None and m.group(1) in fields:
+            cur[fields[m.group(1)]] = int(m.group(2))
+    return out
+
+
+def check_no_spills(usage, source: str) -> None:
+    """A shipped kernel that spills runs from scratch memory: refuse to build it (an unreachable instantiation that
+    spills is dead weight one dispatch typo away from running - delete it instead)."""
+    bad = {k: v for k, v in usage.items() if v.get("vgpr_spill", 0) or v.get("sgpr_spill", 0) or v.get("scratch", 0)}
+    if bad:
+        lines = [f"  {k}: {v}" for k, v in sorted(bad.items())]
+        raise RuntimeError(f"{source}: {len(bad)} kernel(s) spill registers / use scratch:\n" + "\n".join(lines))
+
+
+def _compile_one(src: str, obj: str, extra) -> dict:
+    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", "-ffp-contract=off", "-fvisibility=hidden",
+           "-Wall", "-Wextra", "-Rpass-analysis=kernel-resource-usage", *HIPCC_FLAGS, *extra, f"-I{INCLUDE}", f"-I{CSRC}", src,
+           "-o", obj]
+    print("+", " ".join(shlex.quote(c) for c in cmd), flush=True)
+    p = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
+    diag = "\n".join(l for l in p.stderr.splitlines() if "-Rpass-analysis" not in l and not l.lstrip().startswith(("|", "^"))
+                     and not __import__("re").match(r"\s*\d+ \|", l))
+    if diag.strip():
+        print(diag, file=sys.stderr, flush=True)
+    if p.returncode != 0:
+        raise subprocess.CalledProcessError(p.returncode, cmd)
+    usage = parse_resource_usage(p.stderr)
+    check_no_spills(usage, os.path.basename(src))
+    return usage
+
+
 def build_hip_lib(force: bool = False) -> str:
     srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
     deps = srcs + [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HIP_HEADERS] + [os.path.abspath(__file__)]
     if force or _stale(HIP_LIB, deps):
+        import json
+        from concurrent.futures import ThreadPoolExecutor
+
         os.makedirs(LIB_DIR, exist_ok=True)
+        os.makedirs(OBJ_DIR, exist_ok=True)
         extra = shlex.split(os.environ.get("FP4_EXTRA_HIPCC_FLAGS", ""))  # experiments only
-        _run([_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-              "-fvisibility=hidden", "-Wall", "-Wextra", *HIPCC_FLAGS, *extra, f"-I{INCLUDE}", f"-I{CSRC}", *srcs, "-o", HIP_LIB])
+        objs = [os.path.join(OBJ_DIR, os.path.basename(s) + ".o") for s in srcs]
+        # one translation unit per source, compiled side by side; every kernel's register / scratch use is checked
+        with ThreadPoolExecutor(max_workers=min(len(srcs), os.cpu_count() or 1)) as pool:
+            usages = list(pool.map(lambda so: _compile_one(so[0], so[1], extra), zip(srcs, objs)))
+        _run([_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-fvisibility=hidden", *objs, "-o", HIP_LIB])
+        merged = {k: v for u in usages for k, v in u.items()}
+        with open(os.path.join(LIB_DIR, "kernel_resources.json"), "w") as f:
+            json.dump(merged, f, indent=0, sort_keys=True)
+        print(f"{len(merged)} kernels, none spills", flush=True)
     return HIP_LIB
 
 

@@ -1,4 +1,5 @@
 // Status plumbing and the small host-only entry points of the C ABI (include/torch_bnb_fp4_hip.h).
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -34,15 +35,15 @@ int check_launch(const char *what) {
 
 // Compute units of the current device (256 on MI355X), cached per device ordinal; used to size persistent grids.
 int device_cu_count() {
-    static int cached[64] = {};
+    static std::atomic<int> cached[64] = {};  // racing first calls both query and store the same value
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
-    if (cached[dev] == 0) {
-        int cus = 0;
+    int cus = cached[dev].load(std::memory_order_relaxed);
+    if (cus == 0) {
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-        cached[dev] = cus;
+        cached[dev].store(cus, std::memory_order_relaxed);
     }
-    return cached[dev];
+    return cus;
 }
 
 }  // namespace fp4

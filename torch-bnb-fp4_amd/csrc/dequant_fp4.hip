@@ -18,6 +18,8 @@
 //    packed loads in flight.  Large outputs use non-temporal loads and stores (streamed once).
 //  * One launch covers all whole tiles; a small generic kernel covers the ragged tail, odd
 //    alignments and unusual block sizes with the reference's exact absmax-index rule.
+#include <atomic>
+
 #include "fp4_common.h"
 
 namespace fp4 {
@@ -144,7 +146,7 @@ __global__ __launch_bounds__(kThreads) void dequant_generic_kernel(const uint8_t
     }
 }
 
-int g_dequant_variant = -1;  // LOADS | NT << 8, or -1 = heuristic
+std::atomic<int> g_dequant_variant{-1};  // sweep hook: LOADS | NT << 8, or -1 = heuristic (relaxed atomic, one snapshot per call)
 
 template <int DT, int LOADS, bool NT>
 void launch_tiles(const uint8_t *packed, const float *absmax, void *out, int bs_shift, int64_t tiles, int which_table,
@@ -159,9 +161,10 @@ int64_t run_tiles(const uint8_t *packed, const float *absmax, void *out, int bs_
     constexpr int kVals = OutCfg<DT>::kVals;
     int loads;
     bool nt;
-    if (g_dequant_variant >= 0) {
-        loads = g_dequant_variant & 0xFF;
-        nt = (g_dequant_variant >> 8) & 1;
+    const int gv = g_dequant_variant.load(std::memory_order_relaxed);
+    if (gv >= 0) {
+        loads = gv & 0xFF;
+        nt = (gv >> 8) & 1;
     } else {
         // Measured on MI355X at 4096x4096 (profiles/r01_*): 4 loads per lane (2048 workgroups = 8 per CU, one
         // resident round) with non-temporal loads AND stores is the fastest 16-bit geometry (7.5 us vs 9.7 us
@@ -208,7 +211,7 @@ int run(const uint8_t *packed, const float *absmax, void *out, int blocksize, in
     if (bs_shift >= 5 && (align & 15u) == 0) {
         done = run_tiles<DT>(packed, absmax, out, bs_shift, n, which_table, flags, stream);
         if (done < 0) {
-            set_error("fp4_hip_dequantize_blockwise: unknown kernel variant %d", g_dequant_variant);
+            set_error("fp4_hip_dequantize_blockwise: unknown kernel variant %d", g_dequant_variant.load(std::memory_order_relaxed));
             return FP4_ERR_INVALID_ARGUMENT;
         }
     }
@@ -223,7 +226,7 @@ int run(const uint8_t *packed, const float *absmax, void *out, int blocksize, in
 
 }  // namespace
 
-void set_dequant_variant(int v) { g_dequant_variant = v; }
+void set_dequant_variant(int v) { g_dequant_variant.store(v, std::memory_order_relaxed); }
 
 }  // namespace fp4
 

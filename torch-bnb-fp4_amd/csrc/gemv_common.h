@@ -1,0 +1,84 @@
+// Device helpers shared by the fused FP4 GEMV (gemv_fp4.hip) and its small-batch companion (gemm_small_fp4.hip):
+// the table-free nibble decode, v_dot2 wrappers, DPP reductions and the GEMV row epilogue.
+#pragma once
+
+#include "fp4_common.h"
+
+namespace fp4 {
+namespace {
+
+// ---- byte tables for v_perm_b32: magnitude index 0..7 -> 12*|code| --------------------------
+// fp16 patterns 0x0000 0x2C00 0x4800 0x4A00 0x4400 0x4600 0x4000 0x4200 (low byte always 0)
+constexpr uint32_t kF16HiLo = 0x4A482C00u, kF16HiHi = 0x42404644u;
+// bf16 patterns 0x0000 0x3D80 0x4100 0x4140 0x4080 0x40C0 0x4000 0x4040
+constexpr uint32_t kBf16HiLo = 0x41413D00u, kBf16HiHi = 0x40404040u;
+constexpr uint32_t kBf16LoLo = 0x40008000u, kBf16LoHi = 0x4000C080u;
+
+__device__ __forceinline__ uint32_t perm(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
+
+// One packed dword = 8 weights e0..e7 (byte b holds e_2b in its high nibble, e_2b+1 in its low
+// nibble).  Produces four 16-bit pairs of 12*code: P0=(e0,e2) P1=(e4,e6) P2=(e1,e3) P3=(e5,e7).
+template <int DT>
+__device__ __forceinline__ void decode8(uint32_t q, uint32_t (&P)[4]) {
+    const uint32_t lo_sel = q & 0x07070707u;         // magnitudes of e1,e3,e5,e7
+    const uint32_t hi_sel = (q >> 4) & 0x07070707u;  // magnitudes of e0,e2,e4,e6
+    const uint32_t lo_sgn = (q & 0x08080808u) << 4;  // sign -> bit 7 of each byte
+    const uint32_t hi_sgn = q & 0x80808080u;
+    if constexpr (DT == FP4_DTYPE_F16) {
+        const uint32_t mhi = perm(kF16HiHi, kF16HiLo, hi_sel) | hi_sgn;
+        const uint32_t mlo = perm(kF16HiHi, kF16HiLo, lo_sel) | lo_sgn;
+        P[0] = perm(0u, mhi, 0x010C000Cu);
+        P[1] = perm(0u, mhi, 0x030C020Cu);
+        P[2] = perm(0u, mlo, 0x010C000Cu);
+        P[3] = perm(0u, mlo, 0x030C020Cu);
+    } else {
+        const uint32_t hH = perm(kBf16HiHi, kBf16HiLo, hi_sel) | hi_sgn;
+        const uint32_t hL = perm(kBf16LoHi, kBf16LoLo, hi_sel);
+        const uint32_t lH = perm(kBf16HiHi, kBf16HiLo, lo_sel) | lo_sgn;
+        const uint32_t lL = perm(kBf16LoHi, kBf16LoLo, lo_sel);
+        P[0] = perm(hH, hL, 0x05010400u);
+        P[1] = perm(hH, hL, 0x07030602u);
+        P[2] = perm(lH, lL, 0x05010400u);
+        P[3] = perm(lH, lL, 0x07030602u);
+    }
+}
+
+template <int DT>
+__device__ __forceinline__ float dot2(uint32_t a, uint32_t b, float c) {
+    if constexpr (DT == FP4_DTYPE_F16)
+        return __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, a), __builtin_bit_cast(f16x2, b), c, false);
+    else
+        return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, a), __builtin_bit_cast(bf16x2, b), c, false);
+}
+
+// ---- wave64 all-lanes sum without LDS storage -------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+    const int moved = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false);
+    return v + __builtin_bit_cast(float, moved);
+}
+__device__ __forceinline__ float wave_sum(float v) {
+    v = dpp_add<0x128>(v);  // row_ror:8
+    v = dpp_add<0x124>(v);  // row_ror:4
+    v = dpp_add<0x122>(v);  // row_ror:2
+    v = dpp_add<0x121>(v);  // row_ror:1   -> every lane holds its 16-lane row sum
+    v += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));  // lane ^ 16
+    const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+    const float b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+    return a + b;
+}
+
+template <int DT>
+__device__ __forceinline__ void store_row(uint16_t *out, const uint16_t *bias, int row, float sum, int out_f32 = 0) {
+    if (out_f32) {  // K-split partial: the raw f32 accumulator, summed across shards before any rounding
+        reinterpret_cast<float *>(out)[row] = sum;
+        return;
+    }
+    uint16_t t = from_f32<DT>(sum);
+    // reference: out = T(gemv); out += bias  (torch_bnb_fp4/__init__.py:608-613) -> two roundings
+    if (bias) t = from_f32<DT>(to_f32<DT>(t) + to_f32<DT>(bias[row]));
+    out[row] = t;
+}
+
+}  // namespace
+}  // namespace fp4

@@ -25,89 +25,16 @@
 //  * gemv16_regx_kernel   - register-x geometry, the DEFAULT for 16-bit activations: a lane owns the same K-chunks for every
 //                           row of its workgroup, so its slice of x lives in VGPRs; K split into 1..8 bands of 32 chunks,
 //                           one wave per band, the band count chosen so that no lane of a band idles (default_variant16).
-//  * gemm16_small_kernel  - the same with 2..8 activation rows on the VALU (fallback of fp4_hip_gemm_small).
 //  * gemv32_kernel / gemv32_regx_kernel - f32 activations (bit-faithful CODE_PARAM f32 table in LDS).
-//  * gemm16_mfma_kernel / gemm16_mfma_persist_kernel - 2..16 activation rows on the matrix cores (fp4_hip_gemm_small):
-//                           one-shot for any K % 512 == 0, persistent with pass-independent B fragments for K = 4096.
 //  * gemv_generic_kernel  - any even K / blocksize, unaligned operands.
-#include "fp4_common.h"
+// (the 2..64-row small-batch kernels built on the same decode live in gemm_small_fp4.hip)
+#include <atomic>
+
+#include "gemv_common.h"
 
 namespace fp4 {
 
 namespace {
-
-// ---- byte tables for v_perm_b32: magnitude index 0..7 -> 12*|code| --------------------------
-// fp16 patterns 0x0000 0x2C00 0x4800 0x4A00 0x4400 0x4600 0x4000 0x4200 (low byte always 0)
-constexpr uint32_t kF16HiLo = 0x4A482C00u, kF16HiHi = 0x42404644u;
-// bf16 patterns 0x0000 0x3D80 0x4100 0x4140 0x4080 0x40C0 0x4000 0x4040
-constexpr uint32_t kBf16HiLo = 0x41413D00u, kBf16HiHi = 0x40404040u;
-constexpr uint32_t kBf16LoLo = 0x40008000u, kBf16LoHi = 0x4000C080u;
-
-__device__ __forceinline__ uint32_t perm(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
-
-// One packed dword = 8 weights e0..e7 (byte b holds e_2b in its high nibble, e_2b+1 in its low
-// nibble).  Produces four 16-bit pairs of 12*code: P0=(e0,e2) P1=(e4,e6) P2=(e1,e3) P3=(e5,e7).
-template <int DT>
-__device__ __forceinline__ void decode8(uint32_t q, uint32_t (&P)[4]) {
-    const uint32_t lo_sel = q & 0x07070707u;         // magnitudes of e1,e3,e5,e7
-    const uint32_t hi_sel = (q >> 4) & 0x07070707u;  // magnitudes of e0,e2,e4,e6
-    const uint32_t lo_sgn = (q & 0x08080808u) << 4;  // sign -> bit 7 of each byte
-    const uint32_t hi_sgn = q & 0x80808080u;
-    if constexpr (DT == FP4_DTYPE_F16) {
-        const uint32_t mhi = perm(kF16HiHi, kF16HiLo, hi_sel) | hi_sgn;
-        const uint32_t mlo = perm(kF16HiHi, kF16HiLo, lo_sel) | lo_sgn;
-        P[0] = perm(0u, mhi, 0x010C000Cu);
-        P[1] = perm(0u, mhi, 0x030C020Cu);
-        P[2] = perm(0u, mlo, 0x010C000Cu);
-        P[3] = perm(0u, mlo, 0x030C020Cu);
-    } else {
-        const uint32_t hH = perm(kBf16HiHi, kBf16HiLo, hi_sel) | hi_sgn;
-        const uint32_t hL = perm(kBf16LoHi, kBf16LoLo, hi_sel);
-        const uint32_t lH = perm(kBf16HiHi, kBf16HiLo, lo_sel) | lo_sgn;
-        const uint32_t lL = perm(kBf16LoHi, kBf16LoLo, lo_sel);
-        P[0] = perm(hH, hL, 0x05010400u);
-        P[1] = perm(hH, hL, 0x07030602u);
-        P[2] = perm(lH, lL, 0x05010400u);
-        P[3] = perm(lH, lL, 0x07030602u);
-    }
-}
-
-template <int DT>
-__device__ __forceinline__ float dot2(uint32_t a, uint32_t b, float c) {
-    if constexpr (DT == FP4_DTYPE_F16)
-        return __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, a), __builtin_bit_cast(f16x2, b), c, false);
-    else
-        return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, a), __builtin_bit_cast(bf16x2, b), c, false);
-}
-
-// ---- wave64 all-lanes sum without LDS storage -------------------------------------------------
-template <int CTRL>
-__device__ __forceinline__ float dpp_add(float v) {
-    const int moved = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false);
-    return v + __builtin_bit_cast(float, moved);
-}
-__device__ __forceinline__ float wave_sum(float v) {
-    v = dpp_add<0x128>(v);  // row_ror:8
-    v = dpp_add<0x124>(v);  // row_ror:4
-    v = dpp_add<0x122>(v);  // row_ror:2
-    v = dpp_add<0x121>(v);  // row_ror:1   -> every lane holds its 16-lane row sum
-    v += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));  // lane ^ 16
-    const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
-    const float b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
-    return a + b;
-}
-
-template <int DT>
-__device__ __forceinline__ void store_row(uint16_t *out, const uint16_t *bias, int row, float sum, int out_f32 = 0) {
-    if (out_f32) {  // K-split partial: the raw f32 accumulator, summed across shards before any rounding
-        reinterpret_cast<float *>(out)[row] = sum;
-        return;
-    }
-    uint16_t t = from_f32<DT>(sum);
-    // reference: out = T(gemv); out += bias  (torch_bnb_fp4/__init__.py:608-613) -> two roundings
-    if (bias) t = from_f32<DT>(to_f32<DT>(t) + to_f32<DT>(bias[row]));
-    out[row] = t;
-}
 
 // ---- 16-bit activations: the decode path -----------------------------------------------------
 // LDS image of x: group g (8 values) of chunk c sits at 16-byte slot [g*C + c], holding the
@@ -621,7 +548,9 @@ int dispatch32_regx(bool perm, int iters, const void *x, const uint8_t *W, const
         case 1: return launch32_regx<KS, GG, 1, PERM>(x, W, absmax, bias, out, M, K, bs_shift, stream);        \
         case 2: return launch32_regx<KS, GG, 2, PERM>(x, W, absmax, bias, out, M, K, bs_shift, stream);        \
         case 4: return launch32_regx<KS, GG, 4, PERM>(x, W, absmax, bias, out, M, K, bs_shift, stream);        \
-        default: return launch32_regx<KS, GG, 8, PERM>(x, W, absmax, bias, out, M, K, bs_shift, stream);       \
+        default:                                                                                               \
+            if constexpr ((GG) == 1) return launch32_regx<KS, GG, 8, PERM>(x, W, absmax, bias, out, M, K, bs_shift, stream); \
+            return launch32_regx<KS, GG, 4, PERM>(x, W, absmax, bias, out, M, K, bs_shift, stream);            \
     }
 #define FP4_R32(KS, GG)          \
     if (perm) {                  \
@@ -675,8 +604,9 @@ __global__ __launch_bounds__(256) void gemv_generic_kernel(const void *__restric
     }
 }
 
-int g_small_variant = -1;  // fp4_hip_gemm_small: -1 heuristic, 0 VALU kernel, 1 matrix-core kernel (sweeps)
-int g_gemv_variant = -1;  // LDS geometry: ROWS | WAVES << 8 | UNROLL << 16; register-x geometry: 1 << 24 | KSPLIT_override << 8 | ITERS; -1 = heuristic
+// LDS geometry: ROWS | WAVES << 8 | UNROLL << 16; register-x geometry: 1 << 24 | KSPLIT_override << 8 | ITERS; -1 = heuristic.
+// Sweep hook only (fp4_hip_set_variant); relaxed atomic so that a server thread launching while a sweep flips it is not a data race.
+std::atomic<int> g_gemv_variant{-1};
 
 constexpr int kMaxLdsBytes = 160 * 1024 - 256;
 
@@ -721,660 +651,6 @@ int dispatch16(int variant, const void *x, const uint8_t *W, const float *absmax
 }
 
 constexpr int kRegxFlag = 1 << 24;
-
-// ---- small batch (2..8 activation rows): the same register-x geometry with NB x-slices per lane ----------
-// The reference sends every batch > 1 through a full dequant (43 MB written and re-read at 4096x4096) plus a dense
-// GEMM (torch_bnb_fp4/__init__.py:616-617).  For a handful of rows the weight stream can instead be decoded once
-// per nibble and dotted against NB activation rows: traffic stays at the GEMV's 9.45 MB.  One rounding at the end,
-// bias added in f32 before it (what F.linear does for batch > 1).
-template <int DT, int KSPLIT, int G, int ITERS, int NB>
-__global__ __launch_bounds__(256) void gemm16_small_kernel(const uint16_t *__restrict__ x, const uint8_t *__restrict__ W,
-                                                           const float *__restrict__ absmax,
-                                                           const uint16_t *__restrict__ bias, uint16_t *__restrict__ out,
-                                                           int B, int M, int K, int bs_shift) {
-    constexpr int RG = 4 / KSPLIT;
-    constexpr int kRowsPerBlock = 2 * RG * ITERS;
-    __shared__ float s_part[kRowsPerBlock][KSPLIT][NB];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int kw = wave % KSPLIT, rw = wave / KSPLIT;
-    const int half = lane >> 5, l32 = lane & 31;
-    const int C = K >> 5;
-    const int row_base = blockIdx.x * kRowsPerBlock;
-    const u32x4 *Wv = reinterpret_cast<const u32x4 *>(W);
-
-    int cidx[G];
-    bool live[G];
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-        const int c = g * (32 * KSPLIT) + kw * 32 + l32;
-        live[g] = c < C;
-        cidx[g] = live[g] ? c : C - 1;
-    }
-    u32x4 xd[NB][G][4];
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-        const int64_t xrow = int64_t(b < B ? b : B - 1) * (K >> 3);  // in 16-byte pieces; rows past B are computed, not stored
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) xd[b][g][q] = reinterpret_cast<const u32x4 *>(x)[xrow + cidx[g] * 4 + q];
-        }
-    }
-    u32x4 wq[ITERS][G];
-    float am[ITERS][G];
-    int rowi[ITERS];
-#pragma unroll
-    for (int it = 0; it < ITERS; ++it) {
-        const int local = 2 * (it * RG + rw) + half;
-        const int row = row_base + local;
-        rowi[it] = local;
-        const int rclamp = row < M ? row : M - 1;
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-            const int64_t chunk = int64_t(rclamp) * C + cidx[g];
-            wq[it][g] = __builtin_nontemporal_load(Wv + chunk);
-            const float a = absmax[(chunk << 5) >> bs_shift];
-            am[it][g] = live[g] ? a : 0.0f;
-        }
-    }
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const u32x4 w = xd[b][g][q];
-                xd[b][g][q].x = perm(w.y, w.x, 0x05040100u);
-                xd[b][g][q].y = perm(w.w, w.z, 0x05040100u);
-                xd[b][g][q].z = perm(w.y, w.x, 0x07060302u);
-                xd[b][g][q].w = perm(w.w, w.z, 0x07060302u);
-            }
-        }
-    }
-#pragma unroll
-    for (int it = 0; it < ITERS; ++it) {
-        float p[NB];
-#pragma unroll
-        for (int b = 0; b < NB; ++b) p[b] = 0.0f;
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-            float s[NB];
-#pragma unroll
-            for (int b = 0; b < NB; ++b) s[b] = 0.0f;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                uint32_t P[4];
-                decode8<DT>(wq[it][g][q], P);  // decoded once, used by every activation row
-#pragma unroll
-                for (int b = 0; b < NB; ++b) {
-                    s[b] = dot2<DT>(P[0], xd[b][g][q].x, s[b]);
-                    s[b] = dot2<DT>(P[1], xd[b][g][q].y, s[b]);
-                    s[b] = dot2<DT>(P[2], xd[b][g][q].z, s[b]);
-                    s[b] = dot2<DT>(P[3], xd[b][g][q].w, s[b]);
-                }
-            }
-#pragma unroll
-            for (int b = 0; b < NB; ++b) p[b] = __builtin_fmaf(s[b], am[it][g], p[b]);
-        }
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            float v = p[b];
-            v = dpp_add<0x128>(v);
-            v = dpp_add<0x124>(v);
-            v = dpp_add<0x122>(v);
-            v = dpp_add<0x121>(v);
-            v += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));
-            if (l32 == 0) s_part[rowi[it]][kw][b] = v;
-        }
-    }
-    __syncthreads();
-    for (int i = tid; i < kRowsPerBlock * NB; i += 256) {
-        const int r = i / NB, b = i % NB;
-        float t = 0.0f;
-#pragma unroll
-        for (int k = 0; k < KSPLIT; ++k) t += s_part[r][k][b];
-        const int row = row_base + r;
-        if (row < M && b < B) {
-            t *= (1.0f / 12.0f);
-            if (bias) t += to_f32<DT>(bias[row]);
-            out[int64_t(b) * M + row] = from_f32<DT>(t);
-        }
-    }
-}
-
-// ---- small batch on the matrix cores (2..16 activation rows) -----------------------------------------------------
-// With up to 16 activation rows the product is GEMM-shaped enough for v_mfma_f32_16x16x32: M-dim = 16 weight rows,
-// N-dim = the (up to 16) activation rows, K-dim = 32 weights.  The dot work moves from the VALU to the matrix pipe, so
-// the cost no longer grows with the batch (the VALU small-batch kernel above pays 4 v_dot2 per row per 8 weights);
-// the VALU only decodes (decode8: the four dwords it returns ARE the A fragment, with the k order of the 8-group
-// permuted the same way on the B side).
-//   * workgroup = 8 waves = one 16-row tile of W; the 8 waves split K (wave w owns quant blocks w*NBW.. of every pass);
-//   * lane (r = l&15, kb = l>>4) supplies, per 64-weight quant block, the 8 packed bytes [8kb, 8kb+8) of row r: two
-//     MFMAs per block (k-sets {16kb + 8t + j}), so one MFMA never straddles two scales; the block's partial tile is
-//     scaled by absmax[row(reg), block] and added to the f32 accumulator (4 FMAs per 2 MFMAs);
-//   * the B operand is x[n = l&15][64b + 16kb + 8t + j], loaded straight from L2 into VGPRs (32 B per block);
-//   * the 8 partial 16x16 tiles meet in LDS; one rounding, bias added in f32 first (F.linear semantics).
-// Needs blocksize 64 and K a multiple of 512; everything else is served by the kernels above or by dequant + GEMM.
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
-
-template <int DT>
-__device__ __forceinline__ f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c) {
-    if constexpr (DT == FP4_DTYPE_F16)
-        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
-    else
-        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
-}
-
-// 8 consecutive 16-bit activations (x0..x7) -> the dword order decode8's pairs multiply with: (x0,x2) (x4,x6) (x1,x3) (x5,x7)
-__device__ __forceinline__ u32x4 pair_up8(u32x4 w) {
-    u32x4 o;
-    o.x = perm(w.y, w.x, 0x05040100u);
-    o.y = perm(w.w, w.z, 0x05040100u);
-    o.z = perm(w.y, w.x, 0x07060302u);
-    o.w = perm(w.w, w.z, 0x07060302u);
-    return o;
-}
-
-template <int DT, int NBW, int ROWT, bool STAGE, int XS = 0>
-__global__ __launch_bounds__(512) void gemm16_mfma_kernel(const uint16_t *__restrict__ x, const uint8_t *__restrict__ W,
-                                                          const float *__restrict__ absmax,
-                                                          const uint16_t *__restrict__ bias, uint16_t *__restrict__ out,
-                                                          int B, int M, int K) {
-    // ROWT 16-row tiles per workgroup share one B fragment (x slice): x is re-read by every workgroup, so taller
-    // workgroups cut that L2 traffic (B*K*2 bytes each) at the price of fewer workgroups
-    // STAGE: the A-fragment layout wants 8 bytes per lane from 16 different rows (32-byte segments per row per
-    // instruction); instead each wave pulls its 16 x (32*NBW)-byte region with row-contiguous 16-byte loads and
-    // re-reads it from a wave-private LDS image (no workgroup barrier).  Each image row is followed by that row's NBW
-    // block scales: the accumulator layout needs the scales of 4 rows x NBW blocks per lane, the same values in 16 lanes,
-    // so they are fetched once per wave (one 4- or 8-byte load per lane) and re-read from LDS as broadcasts instead of
-    // 8 x 16-byte global loads per lane and tile.  Row stride 32*NBW + 32 bytes: the 8-byte fragment reads of 16 rows
-    // x 4 k-groups fall on distinct banks per half-wave.
-    // XS > 0 (batch <= XS, XS in {4, 8}): the B fragment wants 32 bytes per lane from 16 activation rows, of which only
-    // `batch` are real - loaded straight from global every 16-row workgroup would pull 16 / batch times its share of x
-    // through the texture path (4x the weight stream at batch 4).  Instead the wave copies the XS x (64*NBW) activations of
-    // its K slice into a wave-private LDS image with row-contiguous 16-byte loads and reads the fragments from there
-    // (lanes of the unused columns read a real row: broadcast, results never stored).
-    constexpr int kStageStride = 32 * NBW + 32;
-    constexpr int kXStride = 128 * NBW + 16;
-    constexpr int kWImageBytes = STAGE ? 8 * ROWT * 16 * kStageStride : 0;
-    constexpr int kXImageBytes = 8 * XS * kXStride;
-    constexpr int kImageBytes = kWImageBytes + kXImageBytes;
-    constexpr int kPartBytes = 8 * ROWT * 256 * 4;
-    static_assert(XS == 0 || (STAGE && (XS * NBW) % 8 == 0 && (XS & (XS - 1)) == 0), "x staging: whole 16-byte units per lane");
-    // the cross-wave partial sums reuse the images' storage after the K loop (one barrier in between): LDS per workgroup
-    // decides how many of these 8-wave workgroups a CU holds
-    __shared__ __attribute__((aligned(16))) uint8_t s_raw[kImageBytes > kPartBytes ? kImageBytes : kPartBytes];
-    uint8_t *s_w = s_raw;
-    uint8_t *s_x = s_raw + kWImageBytes;
-    float (*s_part)[ROWT][256] = reinterpret_cast<float (*)[ROWT][256]>(s_raw);
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int r = lane & 15, kb = lane >> 4;
-    const int row0 = blockIdx.x * (16 * ROWT);
-    const int nblk = K >> 6;
-    const int passes = nblk / (8 * NBW);
-    const int64_t n_b = r < B ? r : B - 1;  // clamped rows / batch entries are computed, never stored
-    int64_t row_a[ROWT], row_d[ROWT][4];
-#pragma unroll
-    for (int rt = 0; rt < ROWT; ++rt) {
-        row_a[rt] = row0 + 16 * rt + r < M ? row0 + 16 * rt + r : M - 1;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) row_d[rt][g] = row0 + 16 * rt + kb * 4 + g < M ? row0 + 16 * rt + kb * 4 + g : M - 1;
-    }
-    const u32x4 *x4 = reinterpret_cast<const u32x4 *>(x);
-    const u32x2 *W2 = reinterpret_cast<const u32x2 *>(W);
-
-    f32x4 acc[ROWT];
-#pragma unroll
-    for (int rt = 0; rt < ROWT; ++rt) acc[rt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    // With up to 4 blocks per wave and pass (K = 14336 and the like: many short passes) the staged operands - weights, their
-    // scales, for XS > 0 the x slice - are loaded one pass AHEAD: the registers of pass p + 1 are requested as soon as pass p's
-    // have been written to the LDS images and fly while pass p is decoded and multiplied.  With 8 blocks per pass the extra live
-    // registers would cost the second workgroup per CU (128 -> 140..164 VGPRs), so there each pass loads its own.
-    constexpr bool kPassAhead = STAGE && NBW <= 4;
-    constexpr int kXUnits = XS ? XS * NBW / 8 : 1;  // 16-byte units of the x image per lane
-    constexpr int kLanesPerRow = 2 * NBW, kRowsPerInstr = 64 / kLanesPerRow, kInstr = (16 + kRowsPerInstr - 1) / kRowsPerInstr;
-    // 16 rows x NBW scales over 64 lanes (with NBW < 4 the upper lanes repeat rows: same address, same value)
-    constexpr int kScalesPerLane = NBW > 4 ? NBW / 4 : 1;
-    constexpr int kLanesPerScaleRow = NBW / kScalesPerLane;
-    const int srow = (lane / kLanesPerScaleRow) & 15, sj0 = (lane % kLanesPerScaleRow) * kScalesPerLane;
-    u32x4 xstage[kXUnits];
-    u32x4 wstage[ROWT][kInstr];
-    float amstage[ROWT][kScalesPerLane];
-    auto issue_staged = [&](int pass) {  // x first (L2), then the weight stream (HBM), then the scales; all branch-free
-        const int b0 = (pass * 8 + wave) * NBW;
-        if constexpr (XS > 0) {
-#pragma unroll
-            for (int i = 0; i < kXUnits; ++i) {
-                const int u = i * 64 + lane, n = u / (8 * NBW), c16 = u % (8 * NBW);
-                const int64_t nn = n < B ? n : B - 1;
-                xstage[i] = x4[((nn * K + 64 * b0) >> 3) + c16];
-            }
-        }
-#pragma unroll
-        for (int rt = 0; rt < ROWT; ++rt)
-#pragma unroll
-            for (int i = 0; i < kInstr; ++i) {
-                const int rr = i * kRowsPerInstr + lane / kLanesPerRow;  // row of the tile this lane fetches
-                const int64_t row = row0 + 16 * rt + (rr & 15) < M ? row0 + 16 * rt + (rr & 15) : M - 1;
-                wstage[rt][i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(W) + ((row * K) >> 5) + 2 * b0 +
-                                                           (lane % kLanesPerRow));
-            }
-#pragma unroll
-        for (int rt = 0; rt < ROWT; ++rt) {
-            const int64_t row = row0 + 16 * rt + srow < M ? row0 + 16 * rt + srow : M - 1;
-            const float *src = absmax + row * nblk + b0 + sj0;
-#pragma unroll
-            for (int i = 0; i < kScalesPerLane; ++i) amstage[rt][i] = src[i];
-        }
-    };
-    if constexpr (kPassAhead) issue_staged(0);
-    for (int p = 0; p < passes; ++p) {
-        const int b0 = (p * 8 + wave) * NBW;
-        if constexpr (STAGE && !kPassAhead) issue_staged(p);
-        u32x4 xr[XS ? 1 : NBW][2];
-        if constexpr (XS == 0) {
-#pragma unroll
-            for (int j = 0; j < NBW; ++j) {
-                const int64_t e = n_b * K + 64 * (b0 + j) + 16 * kb;
-                xr[j][0] = x4[e >> 3];
-                xr[j][1] = x4[(e >> 3) + 1];
-            }
-        }
-        u32x2 wq[ROWT][NBW];
-        float am[ROWT][4][NBW];
-        if constexpr (!STAGE) {
-#pragma unroll
-            for (int rt = 0; rt < ROWT; ++rt)
-#pragma unroll
-                for (int j = 0; j < NBW; ++j)
-                    wq[rt][j] = __builtin_nontemporal_load(W2 + ((row_a[rt] * K) >> 4) + 4 * (b0 + j) + kb);
-#pragma unroll
-            for (int rt = 0; rt < ROWT; ++rt) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const float *src = absmax + row_d[rt][g] * nblk + b0;
-                    if constexpr (NBW % 4 == 0) {
-#pragma unroll
-                        for (int j = 0; j < NBW; j += 4) {
-                            const f32x4 v = *reinterpret_cast<const f32x4 *>(src + j);
-                            am[rt][g][j] = v.x, am[rt][g][j + 1] = v.y, am[rt][g][j + 2] = v.z, am[rt][g][j + 3] = v.w;
-                        }
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < NBW; ++j) am[rt][g][j] = src[j];
-                    }
-                }
-            }
-        }
-        if constexpr (STAGE) {
-            if (p > 0) __builtin_amdgcn_wave_barrier();  // the previous pass's reads are done before the image is rewritten
-#pragma unroll
-            for (int rt = 0; rt < ROWT; ++rt) {
-                uint8_t *img = s_w + (wave * ROWT + rt) * 16 * kStageStride;
-#pragma unroll
-                for (int i = 0; i < kInstr; ++i) {
-                    const int rr = i * kRowsPerInstr + lane / kLanesPerRow;
-                    if (rr < 16) *reinterpret_cast<u32x4 *>(img + rr * kStageStride + 16 * (lane % kLanesPerRow)) = wstage[rt][i];
-                }
-                float *tail = reinterpret_cast<float *>(img + srow * kStageStride + 32 * NBW) + sj0;
-#pragma unroll
-                for (int i = 0; i < kScalesPerLane; ++i) tail[i] = amstage[rt][i];
-            }
-            if constexpr (XS > 0) {
-                uint8_t *ximg = s_x + wave * XS * kXStride;
-#pragma unroll
-                for (int i = 0; i < kXUnits; ++i) {
-                    const int u = i * 64 + lane, n = u / (8 * NBW), c16 = u % (8 * NBW);
-                    *reinterpret_cast<u32x4 *>(ximg + n * kXStride + 16 * c16) = pair_up8(xstage[i]);  // once, not per tile
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if constexpr (kPassAhead)
-                if (p + 1 < passes) issue_staged(p + 1);  // uniform
-#pragma unroll
-            for (int rt = 0; rt < ROWT; ++rt) {
-                const uint8_t *img = s_w + (wave * ROWT + rt) * 16 * kStageStride;
-#pragma unroll
-                for (int j = 0; j < NBW; ++j) wq[rt][j] = *reinterpret_cast<const u32x2 *>(img + r * kStageStride + 32 * j + 8 * kb);
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const uint8_t *src = img + (kb * 4 + g) * kStageStride + 32 * NBW;
-                    if constexpr (NBW % 4 == 0) {
-#pragma unroll
-                        for (int j = 0; j < NBW; j += 4) {
-                            const f32x4 v = reinterpret_cast<const f32x4 *>(src)[j >> 2];
-                            am[rt][g][j] = v.x, am[rt][g][j + 1] = v.y, am[rt][g][j + 2] = v.z, am[rt][g][j + 3] = v.w;
-                        }
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < NBW; ++j) am[rt][g][j] = reinterpret_cast<const float *>(src)[j];
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < NBW; ++j) {
-            u32x4 bfrag[2];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                if constexpr (XS > 0)
-                    bfrag[t] = *reinterpret_cast<const u32x4 *>(s_x + wave * XS * kXStride + (r & (XS - 1)) * kXStride + 128 * j + 32 * kb + 16 * t);
-                else
-                    bfrag[t] = pair_up8(xr[j][t]);
-            }
-#pragma unroll
-            for (int rt = 0; rt < ROWT; ++rt) {
-                f32x4 tile = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    uint32_t P[4];
-                    decode8<DT>(t == 0 ? wq[rt][j].x : wq[rt][j].y, P);
-                    const u32x4 afrag = {P[0], P[1], P[2], P[3]};
-                    tile = mfma16<DT>(afrag, bfrag[t], tile);
-                }
-                acc[rt].x = __builtin_fmaf(tile.x, am[rt][0][j], acc[rt].x);
-                acc[rt].y = __builtin_fmaf(tile.y, am[rt][1][j], acc[rt].y);
-                acc[rt].z = __builtin_fmaf(tile.z, am[rt][2][j], acc[rt].z);
-                acc[rt].w = __builtin_fmaf(tile.w, am[rt][3][j], acc[rt].w);
-            }
-        }
-    }
-    if constexpr (STAGE) __syncthreads();  // every wave is done with its image before the partials overwrite the storage
-#pragma unroll
-    for (int rt = 0; rt < ROWT; ++rt) *reinterpret_cast<f32x4 *>(&s_part[wave][rt][lane * 4]) = acc[rt];
-    __syncthreads();
-    for (int i = tid; i < ROWT * 256; i += 512) {
-        const int rt = i >> 8, e = i & 255;
-        float t = 0.0f;
-#pragma unroll
-        for (int w = 0; w < 8; ++w) t += s_part[w][rt][e];
-        const int l = e >> 2, reg = e & 3;  // D layout: col = l & 15 (activation row), row = (l >> 4) * 4 + reg (weight row)
-        const int n = l & 15, row = row0 + 16 * rt + (l >> 4) * 4 + reg;
-        if (row < M && n < B) {
-            t *= (1.0f / 12.0f);
-            if (bias) t += to_f32<DT>(bias[row]);
-            out[int64_t(n) * M + row] = from_f32<DT>(t);
-        }
-    }
-}
-
-// ---- the same tile arithmetic as a PERSISTENT workgroup, for K = 4096 (one pass: 8 waves x 8 blocks) -------------
-// On tall weights the one-shot kernel above runs as three to four generations of 8-wave workgroups, each of which has
-// nothing in flight while it stages, decodes and reduces.  Here a workgroup walks 16-row tiles with stride gridDim.x:
-//   * a wave keeps the same K slice for every tile, so its XS x (512) activations are staged ONCE into its LDS image;
-//   * the next tile's weights and scales (4 + 1 loads per lane) are issued right after the current tile's registers have
-//     been written to the weight image, and fly while the current tile is decoded, multiplied, reduced and stored.
-template <int DT, int XS>
-__global__ __launch_bounds__(512) void gemm16_mfma_persist_kernel(const uint16_t *__restrict__ x, const uint8_t *__restrict__ W,
-                                                                  const float *__restrict__ absmax,
-                                                                  const uint16_t *__restrict__ bias, uint16_t *__restrict__ out,
-                                                                  int B, int M, int K, int ntiles) {
-    constexpr int NBW = 8;
-    constexpr int kStageStride = 32 * NBW + 32, kXStride = 128 * NBW + 16;
-    constexpr int kXUnits = XS ? XS * NBW / 8 : 1;
-    __shared__ __attribute__((aligned(16))) uint8_t s_w[8 * 16 * kStageStride];
-    __shared__ __attribute__((aligned(16))) uint8_t s_x[XS ? 8 * XS * kXStride : 16];
-    __shared__ __attribute__((aligned(16))) float s_part[8][256];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 15, kb = lane >> 4;
-    const int nblk = K >> 6;
-    const int b0 = wave * NBW;
-    const u32x4 *x4 = reinterpret_cast<const u32x4 *>(x);
-    uint8_t *img = s_w + wave * 16 * kStageStride;
-    uint8_t *ximg = s_x + wave * XS * kXStride;
-
-    // x slice of this wave, once: up to 8 rows as a paired-up LDS image; above that (XS == 0) the 16 B fragments of the slice
-    // stay in registers for every tile (64 VGPRs: one workgroup per CU, but no x traffic at all after the first tile)
-    u32x4 bregs[XS ? 1 : NBW][2];
-    if constexpr (XS == 0) {
-        const int64_t n_b = r < B ? r : B - 1;
-#pragma unroll
-        for (int j = 0; j < NBW; ++j) {
-            const int64_t e = n_b * K + 64 * (b0 + j) + 16 * kb;
-            bregs[j][0] = pair_up8(x4[e >> 3]);
-            bregs[j][1] = pair_up8(x4[(e >> 3) + 1]);
-        }
-    } else {
-        u32x4 xstage[kXUnits];
-#pragma unroll
-        for (int i = 0; i < kXUnits; ++i) {
-            const int u = i * 64 + lane, n = u / (8 * NBW), c16 = u % (8 * NBW);
-            const int64_t nn = n < B ? n : B - 1;
-            xstage[i] = x4[((nn * K + 64 * b0) >> 3) + c16];
-        }
-#pragma unroll
-        for (int i = 0; i < kXUnits; ++i) {
-            const int u = i * 64 + lane, n = u / (8 * NBW), c16 = u % (8 * NBW);
-            *reinterpret_cast<u32x4 *>(ximg + n * kXStride + 16 * c16) = pair_up8(xstage[i]);
-        }
-    }
-
-    constexpr int kLanesPerRow = 2 * NBW, kRowsPerInstr = 64 / kLanesPerRow, kInstr = 16 / kRowsPerInstr;  // 16, 4, 4
-    constexpr int kScalesPerLane = NBW / 4;
-    const int srow = lane >> 2, sj0 = (lane & 3) * kScalesPerLane;
-    u32x4 wstage[kInstr];
-    float amstage[kScalesPerLane];
-    auto issue = [&](int tile) {  // branch-free: rows past M are clamped (computed, never stored)
-        const int row0 = tile * 16;
-#pragma unroll
-        for (int i = 0; i < kInstr; ++i) {
-            const int rr = i * kRowsPerInstr + lane / kLanesPerRow;
-            const int64_t row = row0 + rr < M ? row0 + rr : M - 1;
-            wstage[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(W) + ((row * K) >> 5) + 2 * b0 + (lane % kLanesPerRow));
-        }
-        const int64_t row = row0 + srow < M ? row0 + srow : M - 1;
-        const float *src = absmax + row * nblk + b0 + sj0;
-#pragma unroll
-        for (int i = 0; i < kScalesPerLane; ++i) amstage[i] = src[i];
-    };
-
-    int tile = blockIdx.x;
-    issue(tile);
-    while (true) {
-        __builtin_amdgcn_wave_barrier();  // this wave's reads of the previous tile's image are done
-#pragma unroll
-        for (int i = 0; i < kInstr; ++i) {
-            const int rr = i * kRowsPerInstr + lane / kLanesPerRow;
-            *reinterpret_cast<u32x4 *>(img + rr * kStageStride + 16 * (lane % kLanesPerRow)) = wstage[i];
-        }
-        {
-            float *tail = reinterpret_cast<float *>(img + srow * kStageStride + 32 * NBW) + sj0;
-#pragma unroll
-            for (int i = 0; i < kScalesPerLane; ++i) tail[i] = amstage[i];
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-        const int next = tile + gridDim.x;
-        const bool has_next = next < ntiles;  // uniform
-        if (has_next) issue(next);
-
-        u32x2 wq[NBW];
-        float am[4][NBW];
-#pragma unroll
-        for (int j = 0; j < NBW; ++j) wq[j] = *reinterpret_cast<const u32x2 *>(img + r * kStageStride + 32 * j + 8 * kb);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 *src = reinterpret_cast<const f32x4 *>(img + (kb * 4 + g) * kStageStride + 32 * NBW);
-#pragma unroll
-            for (int j = 0; j < NBW; j += 4) {
-                const f32x4 v = src[j >> 2];
-                am[g][j] = v.x, am[g][j + 1] = v.y, am[g][j + 2] = v.z, am[g][j + 3] = v.w;
-            }
-        }
-        f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-        for (int j = 0; j < NBW; ++j) {
-            f32x4 t16 = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                u32x4 bfrag;
-                if constexpr (XS == 0)
-                    bfrag = bregs[j][t];
-                else
-                    bfrag = *reinterpret_cast<const u32x4 *>(ximg + (r & (XS - 1)) * kXStride + 128 * j + 32 * kb + 16 * t);
-                uint32_t P[4];
-                decode8<DT>(t == 0 ? wq[j].x : wq[j].y, P);
-                const u32x4 afrag = {P[0], P[1], P[2], P[3]};
-                t16 = mfma16<DT>(afrag, bfrag, t16);
-            }
-            acc.x = __builtin_fmaf(t16.x, am[0][j], acc.x);
-            acc.y = __builtin_fmaf(t16.y, am[1][j], acc.y);
-            acc.z = __builtin_fmaf(t16.z, am[2][j], acc.z);
-            acc.w = __builtin_fmaf(t16.w, am[3][j], acc.w);
-        }
-        *reinterpret_cast<f32x4 *>(&s_part[wave][lane * 4]) = acc;
-        __syncthreads();
-        if (tid < 256) {
-            float t = 0.0f;
-#pragma unroll
-            for (int w = 0; w < 8; ++w) t += s_part[w][tid];
-            const int l = tid >> 2, reg = tid & 3;  // D layout: col = l & 15 (activation row), row = (l >> 4) * 4 + reg
-            const int n = l & 15, row = tile * 16 + (l >> 4) * 4 + reg;
-            if (row < M && n < B) {
-                t *= (1.0f / 12.0f);
-                if (bias) t += to_f32<DT>(bias[row]);
-                out[int64_t(n) * M + row] = from_f32<DT>(t);
-            }
-        }
-        __syncthreads();  // s_part is rewritten by the next tile
-        if (!has_next) break;
-        tile = next;
-    }
-}
-
-int g_mfma_rowt = -1;   // sweeps: force 1 or 2 row tiles per workgroup
-int g_mfma_stage = -1;  // sweeps: 0 = direct 8-byte weight loads, otherwise LDS-staged 16-byte loads
-int g_mfma_xstage = -1;  // sweeps: 0 = B fragments straight from global even for batch <= 8
-int g_mfma_persist = -1;  // sweeps: 0 = never the persistent kernel, 1 = whenever it applies (K = 4096, batch <= 4)
-int g_mfma_nbw4 = -1;     // sweeps: 1 = at most 4 blocks per wave and pass (pass-ahead loads), 0 = 8 wherever they divide K
-
-template <int DT>
-int dispatch_mfma(const void *x, const uint8_t *W, const float *absmax, const void *bias, void *out, int B, int M, int K,
-                  hipStream_t stream) {
-    if (K % 512) return -1;
-    const int units = K / 512;  // quant blocks per wave over the whole K
-    // Measured (profiles/r01_f_small_batch_shapes.txt): two row tiles per workgroup (x fetched once per 32 rows) only pay
-    // for more than 4 activation rows on tall weights; at 188 VGPRs they leave one 8-wave workgroup per CU.
-    const int rowt = g_mfma_rowt > 0 ? g_mfma_rowt : ((B > 4 && M >= 32 * 256) ? 2 : 1);
-    const unsigned blocks = (unsigned)((M + 16 * rowt - 1) / (16 * rowt));
-    // x staged per wave in LDS: always for <= 4 rows (33 KB, two workgroups per CU still fit); for 5..8 rows (66 KB, one
-    // workgroup per CU) only while the grid is a single round anyway
-    if (g_mfma_persist != 0 && g_mfma_rowt <= 0 && g_mfma_stage != 0 && g_mfma_xstage != 0 && K == 4096) {
-        // Up to 4 rows two workgroups fit a CU (78 KB of LDS each), above that one (111 KB of LDS / 166 VGPRs).
-        const int ntiles = (M + 15) / 16, resident = (B <= 4 ? 2 : 1) * device_cu_count();
-        // measured (profiles/r01_f_small_batch_shapes.txt): never slower than the one-shot kernel, level with it while
-        // every workgroup has a single tile, up to 1.6x faster on tall weights
-        {
-            const dim3 grid(ntiles < resident ? ntiles : resident);
-            if (B <= 4)
-                hipLaunchKernelGGL((gemm16_mfma_persist_kernel<DT, 4>), grid, dim3(512), 0, stream,
-                                   reinterpret_cast<const uint16_t *>(x), W, absmax, reinterpret_cast<const uint16_t *>(bias),
-                                   reinterpret_cast<uint16_t *>(out), B, M, K, ntiles);
-            else if (B <= 8)
-                hipLaunchKernelGGL((gemm16_mfma_persist_kernel<DT, 8>), grid, dim3(512), 0, stream,
-                                   reinterpret_cast<const uint16_t *>(x), W, absmax, reinterpret_cast<const uint16_t *>(bias),
-                                   reinterpret_cast<uint16_t *>(out), B, M, K, ntiles);
-            else
-                hipLaunchKernelGGL((gemm16_mfma_persist_kernel<DT, 0>), grid, dim3(512), 0, stream,
-                                   reinterpret_cast<const uint16_t *>(x), W, absmax, reinterpret_cast<const uint16_t *>(bias),
-                                   reinterpret_cast<uint16_t *>(out), B, M, K, ntiles);
-            return FP4_OK;
-        }
-    }
-    const bool xs4 = g_mfma_xstage != 0 && B <= 4;
-    const bool xs8 = g_mfma_xstage != 0 && !xs4 && B <= 8 && (int)blocks <= device_cu_count();
-#define FP4_MF(NBW, RT)                                                                                               \
-    if (g_mfma_stage == 0) {                                                                                          \
-        hipLaunchKernelGGL((gemm16_mfma_kernel<DT, NBW, RT, false>), dim3(blocks), dim3(512), 0, stream,              \
-                           reinterpret_cast<const uint16_t *>(x), W, absmax, reinterpret_cast<const uint16_t *>(bias), \
-                           reinterpret_cast<uint16_t *>(out), B, M, K);                                               \
-        return FP4_OK;                                                                                                \
-    }                                                                                                                 \
-    if constexpr ((NBW) >= 4) {                                                                                       \
-        if (xs4) {                                                                                                    \
-            hipLaunchKernelGGL((gemm16_mfma_kernel<DT, NBW, RT, true, 4>), dim3(blocks), dim3(512), 0, stream,        \
-                               reinterpret_cast<const uint16_t *>(x), W, absmax,                                      \
-                               reinterpret_cast<const uint16_t *>(bias), reinterpret_cast<uint16_t *>(out), B, M, K); \
-            return FP4_OK;                                                                                            \
-        }                                                                                                             \
-        if (xs8) {                                                                                                    \
-            hipLaunchKernelGGL((gemm16_mfma_kernel<DT, NBW, RT, true, 8>), dim3(blocks), dim3(512), 0, stream,        \
-                               reinterpret_cast<const uint16_t *>(x), W, absmax,                                      \
-                               reinterpret_cast<const uint16_t *>(bias), reinterpret_cast<uint16_t *>(out), B, M, K); \
-            return FP4_OK;                                                                                            \
-        }                                                                                                             \
-    }                                                                                                                 \
-    hipLaunchKernelGGL((gemm16_mfma_kernel<DT, NBW, RT, true>), dim3(blocks), dim3(512), 0, stream,                   \
-                       reinterpret_cast<const uint16_t *>(x), W, absmax, reinterpret_cast<const uint16_t *>(bias),    \
-                       reinterpret_cast<uint16_t *>(out), B, M, K);                                                   \
-    return FP4_OK
-#define FP4_MF_RT(NBW)          \
-    if (rowt == 2) {            \
-        FP4_MF(NBW, 2);         \
-    } else {                    \
-        FP4_MF(NBW, 1);         \
-    }
-    // 8 blocks per wave and pass only where that is the whole K (one pass); with several passes 4 blocks + the pass-ahead loads
-    // win (8192 x 8192 x 4 rows: 12.4 -> 10.6 us, 28672 x 8192: 36 -> 33 us; profiles/r01_f_small_batch_pass_ahead.txt)
-    if (units % 8 == 0 && (g_mfma_nbw4 == 0 || (g_mfma_nbw4 < 0 && units == 8))) { FP4_MF_RT(8) }
-    if (units % 4 == 0) { FP4_MF_RT(4) }
-    if (units % 2 == 0) { FP4_MF_RT(2) }
-    FP4_MF_RT(1)
-#undef FP4_MF_RT
-#undef FP4_MF
-}
-
-template <int DT, int KSPLIT, int G, int ITERS, int NB>
-int launch_small(const void *x, const uint8_t *W, const float *absmax, const void *bias, void *out, int B, int M, int K,
-                 int bs_shift, hipStream_t stream) {
-    constexpr int rows_per_block = 2 * (4 / KSPLIT) * ITERS;
-    const unsigned blocks = (unsigned)((M + rows_per_block - 1) / rows_per_block);
-    hipLaunchKernelGGL((gemm16_small_kernel<DT, KSPLIT, G, ITERS, NB>), dim3(blocks), dim3(256), 0, stream,
-                       reinterpret_cast<const uint16_t *>(x), W, absmax, reinterpret_cast<const uint16_t *>(bias),
-                       reinterpret_cast<uint16_t *>(out), B, M, K, bs_shift);
-    return FP4_OK;
-}
-
-// returns -1 when the shape is outside what the register budget covers (caller falls back to dequant + GEMM)
-template <int DT>
-int dispatch_small(const void *x, const uint8_t *W, const float *absmax, const void *bias, void *out, int B, int M, int K,
-                   int bs_shift, hipStream_t stream) {
-    const int C = K >> 5;
-    const int nb = B <= 2 ? 2 : (B <= 4 ? 4 : 8);
-#define FP4_SM(KS, GG, NBB) return launch_small<DT, KS, GG, 2, NBB>(x, W, absmax, bias, out, B, M, K, bs_shift, stream)
-#define FP4_SM_NB(KS, GG)       \
-    switch (nb) {               \
-        case 2: FP4_SM(KS, GG, 2); \
-        case 4: FP4_SM(KS, GG, 4); \
-        default: FP4_SM(KS, GG, 8); \
-    }
-    if (C <= 32) {
-        FP4_SM_NB(1, 1)
-    } else if (C <= 64) {
-        FP4_SM_NB(2, 1)
-    } else if (C <= 128) {
-        FP4_SM_NB(4, 1)
-    } else if (C <= 256 && nb <= 4) {
-        switch (nb) {
-            case 2: FP4_SM(4, 2, 2);
-            default: FP4_SM(4, 2, 4);
-        }
-    } else if (C <= 512 && nb <= 2) {
-        FP4_SM(4, 4, 2);
-    }
-#undef FP4_SM_NB
-#undef FP4_SM
-    return -1;
-}
 
 template <int DT, int KSPLIT, int G, int ITERS, int WAVES = 4>
 int launch_regx(const void *x, const uint8_t *W, const float *absmax, const void *bias, void *out, int M, int K, int bs_shift,
@@ -1460,15 +736,20 @@ int dispatch_regx(int iters, int ks_override, const void *x, const uint8_t *W, c
     if (g == 2 && iters > 4) iters = 4;
     if (g >= 3 && iters > 2) iters = 2;
 #define FP4_RX(KS, GG, IT) return launch_regx<DT, KS, GG, IT>(x, W, absmax, bias, out, M, K, bs_shift, out_f32, stream)
-#define FP4_RX_IT(KS, GG)              \
-    if (ks == KS && g == GG) {         \
-        switch (iters) {               \
-            case 1: FP4_RX(KS, GG, 1); \
-            case 2: FP4_RX(KS, GG, 2); \
-            case 4: FP4_RX(KS, GG, 4); \
-            case 8: FP4_RX(KS, GG, 8); \
-            default: break;            \
-        }                              \
+    // only the (G, ITERS) pairs the clamps above let through are instantiated: G = 1 -> 1, 2, 4, 8; G = 2 -> 1, 2, 4; G >= 3 -> 1, 2
+#define FP4_RX_IT(KS, GG)                                    \
+    if (ks == KS && g == GG) {                               \
+        switch (iters) {                                     \
+            case 1: FP4_RX(KS, GG, 1);                       \
+            case 2: FP4_RX(KS, GG, 2);                       \
+            case 4:                                          \
+                if constexpr ((GG) <= 2) { FP4_RX(KS, GG, 4); } \
+                break;                                       \
+            case 8:                                          \
+                if constexpr ((GG) == 1) { FP4_RX(KS, GG, 8); } \
+                break;                                       \
+            default: break;                                  \
+        }                                                    \
     }
     FP4_RX_IT(1, 1) FP4_RX_IT(1, 2) FP4_RX_IT(1, 4) FP4_RX_IT(2, 1) FP4_RX_IT(2, 2) FP4_RX_IT(2, 4) FP4_RX_IT(4, 1) FP4_RX_IT(4, 2)
     FP4_RX_IT(4, 3) FP4_RX_IT(4, 4)
@@ -1520,16 +801,7 @@ int run_generic(const void *x, const uint8_t *W, const float *absmax, const void
 
 }  // namespace
 
-void set_gemv_variant(int v) { g_gemv_variant = v; }
-void set_small_variant(int v) {
-    g_small_variant = v < 0 ? -1 : (v & 1);
-    g_mfma_rowt = v < 0 ? -1 : ((v >> 4) & 3);  // bits 4-5: row tiles per workgroup of the matrix-core kernel (0 = auto)
-    if (g_mfma_rowt == 0) g_mfma_rowt = -1;
-    g_mfma_stage = v < 0 ? -1 : ((v >> 8) & 1 ? 0 : 1);  // bit 8: direct (unstaged) weight loads
-    g_mfma_xstage = v < 0 ? -1 : ((v >> 9) & 1 ? 0 : 1);  // bit 9: B fragments straight from global
-    g_mfma_persist = v < 0 ? -1 : ((v >> 10) & 3) == 1 ? 0 : (((v >> 10) & 3) == 2 ? 1 : -1);  // bits 10-11: 1 = off, 2 = force
-    g_mfma_nbw4 = v < 0 ? -1 : ((v >> 14) & 3) == 1 ? 1 : (((v >> 14) & 3) == 2 ? 0 : -1);  // bits 14-15: 1 = 4 blocks per pass, 2 = 8
-}
+void set_gemv_variant(int v) { g_gemv_variant.store(v, std::memory_order_relaxed); }
 
 }  // namespace fp4
 
@@ -1563,8 +835,9 @@ int gemv_entry(const void *x, const uint8_t *packed, const float *absmax, const 
     const bool fast = K > 0 && (K % 32) == 0 && bs_shift >= 5 && (K % blocksize) == 0 && (align & 15u) == 0 &&
                       size_t(K) * esz <= size_t(kMaxLdsBytes);
     int rc = FP4_OK;
+    const int gv = g_gemv_variant.load(std::memory_order_relaxed);  // one snapshot per call
     if (fast && dtype != FP4_DTYPE_F32) {
-        int variant = g_gemv_variant >= 0 ? g_gemv_variant : default_variant16((int)M, (int)K);
+        int variant = gv >= 0 ? gv : default_variant16((int)M, (int)K);
         rc = -1;
         if (variant & kRegxFlag) {
             const int iters = variant & 0xFF, ks_override = (variant >> 8) & 0xF;
@@ -1578,10 +851,10 @@ int gemv_entry(const void *x, const uint8_t *packed, const float *absmax, const 
             rc = dtype == FP4_DTYPE_F16
                      ? dispatch16<FP4_DTYPE_F16>(variant, x, packed, absmax, bias, out, (int)M, (int)K, bs_shift, out_f32, s)
                      : dispatch16<FP4_DTYPE_BF16>(variant, x, packed, absmax, bias, out, (int)M, (int)K, bs_shift, out_f32, s);
-    } else if (fast && g_gemv_variant != 0 &&
+    } else if (fast && gv != 0 &&
                // default: the bit-faithful CODE_PARAM f32 table (the all-f32 reference kernel is accurate to ~1e-7, so the
                // table's 1e-6 deviations from k/12 are visible at f32); variant bit 8 selects the table-free decode (+10 %)
-               dispatch32_regx(g_gemv_variant >= 0 && ((g_gemv_variant >> 8) & 1), g_gemv_variant < 0 ? 0 : (g_gemv_variant & 0xFF), x,
+               dispatch32_regx(gv >= 0 && ((gv >> 8) & 1), gv < 0 ? 0 : (gv & 0xFF), x,
                                packed, absmax, bias, out, (int)M, (int)K, bs_shift, s) == FP4_OK) {
         rc = FP4_OK;  // f32 activations, register-x geometry (variant 0 forces the LDS kernel below, for sweeps)
     } else if (fast) {
@@ -1619,60 +892,4 @@ extern "C" int fp4_hip_gemv(const void *x, const uint8_t *packed, const float *a
 extern "C" int fp4_hip_gemv_partial(const void *x, const uint8_t *packed, const float *absmax, float *out_f32, int64_t M,
                                     int64_t K, int blocksize, int x_dtype, void *stream) {
     return fp4::gemv_entry(x, packed, absmax, nullptr, out_f32, M, K, blocksize, x_dtype, 1, stream);
-}
-
-extern "C" int fp4_hip_gemm_small(const void *x, const uint8_t *packed, const float *absmax, const void *bias, void *out,
-                                  int64_t B, int64_t M, int64_t K, int blocksize, int dtype, void *stream) {
-    using namespace fp4;
-    if (B < 1 || B > 64 || M < 0 || K <= 0) {
-        set_error("fp4_hip_gemm_small: B=%lld M=%lld K=%lld (need 1 <= B <= 64)", (long long)B, (long long)M, (long long)K);
-        return FP4_ERR_INVALID_ARGUMENT;
-    }
-    if (B > 16) {
-        // one launch covers 16 activation rows (the matrix-core tile); more rows are evenly split over several launches,
-        // each streaming the weight once - still ahead of dequant + GEMM while launches x 9.45 MB < the 76 MB the
-        // dequantised weight costs to write and read back
-        if (dtype != FP4_DTYPE_F16 && dtype != FP4_DTYPE_BF16) {
-            set_error("fp4_hip_gemm_small: more than 16 rows need a 16-bit dtype, got %d", dtype);
-            return FP4_ERR_UNSUPPORTED;
-        }
-        const int64_t chunks = (B + 15) / 16, per = (B + chunks - 1) / chunks;
-        for (int64_t b0 = 0; b0 < B; b0 += per) {
-            const int64_t nb = B - b0 < per ? B - b0 : per;
-            const int rc = fp4_hip_gemm_small(static_cast<const uint8_t *>(x) + size_t(b0) * size_t(K) * 2, packed, absmax, bias,
-                                              out ? static_cast<uint8_t *>(out) + size_t(b0) * size_t(M) * 2 : nullptr, nb, M, K,
-                                              blocksize, dtype, stream);
-            if (rc != FP4_OK) return rc;
-        }
-        return FP4_OK;
-    }
-    if (M == 0) return FP4_OK;
-    if (!x || !packed || !absmax || !out) {
-        set_error("fp4_hip_gemm_small: null pointer");
-        return FP4_ERR_INVALID_ARGUMENT;
-    }
-    const int bs_shift = ilog2_exact(blocksize);
-    const uintptr_t align = reinterpret_cast<uintptr_t>(packed) | reinterpret_cast<uintptr_t>(x);
-    const bool ok = (dtype == FP4_DTYPE_F16 || dtype == FP4_DTYPE_BF16) && (K % 32) == 0 && bs_shift >= 5 &&
-                    (K % blocksize) == 0 && (align & 15u) == 0 && M <= (int64_t(1) << 30) && K <= (int64_t(1) << 24);
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    int rc = -1;
-    // matrix-core kernel: blocksize 64, K % 512 == 0; wins from 2 rows up (4.96 vs 5.11 us at 2, 5.0 vs 11.3 us at 8), mandatory above 8
-    const bool mfma_ok = ok && blocksize == 64 && (K % 512) == 0;
-    const bool want_mfma = g_small_variant == 1 || (g_small_variant < 0 && B >= 2);
-    if (mfma_ok && (want_mfma || B > 8))
-        rc = dtype == FP4_DTYPE_F16 ? dispatch_mfma<FP4_DTYPE_F16>(x, packed, absmax, bias, out, (int)B, (int)M, (int)K, s)
-                                    : dispatch_mfma<FP4_DTYPE_BF16>(x, packed, absmax, bias, out, (int)B, (int)M, (int)K, s);
-    if (rc == -1 && ok && B <= 8 && K <= 16384)
-        rc = dtype == FP4_DTYPE_F16 ? dispatch_small<FP4_DTYPE_F16>(x, packed, absmax, bias, out, (int)B, (int)M, (int)K, bs_shift, s)
-                                    : dispatch_small<FP4_DTYPE_BF16>(x, packed, absmax, bias, out, (int)B, (int)M, (int)K, bs_shift, s);
-    if (rc == -1 && mfma_ok)
-        rc = dtype == FP4_DTYPE_F16 ? dispatch_mfma<FP4_DTYPE_F16>(x, packed, absmax, bias, out, (int)B, (int)M, (int)K, s)
-                                    : dispatch_mfma<FP4_DTYPE_BF16>(x, packed, absmax, bias, out, (int)B, (int)M, (int)K, s);
-    if (rc == -1) {
-        set_error("fp4_hip_gemm_small: shape B=%lld M=%lld K=%lld blocksize=%d dtype=%d is not covered; use dequant + GEMM",
-                  (long long)B, (long long)M, (long long)K, blocksize, dtype);
-        return FP4_ERR_UNSUPPORTED;
-    }
-    return check_launch("fp4_hip_gemm_small");
 }

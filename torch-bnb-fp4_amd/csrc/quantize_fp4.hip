@@ -11,6 +11,7 @@
 // one packed dword, so loads and stores are both fully coalesced; the block maximum is a butterfly over
 // the bs/8 lanes that share a block (DPP up to 16 lanes, cross-wave through LDS only for blocksize > 512).
 #include <algorithm>
+#include <atomic>
 
 #include "fp4_common.h"
 
@@ -243,9 +244,9 @@ __global__ __launch_bounds__(kQThreads) void quantize_kernel(const void *__restr
 
 namespace fp4 {
 namespace {
-int g_quant_wg_per_cu = 0;  // 0 = default; experiments: fp4_hip_set_variant("quantize", workgroups per CU)
+std::atomic<int> g_quant_wg_per_cu{0};  // 0 = default; sweeps: fp4_hip_set_variant("quantize", workgroups per CU)
 }
-void set_quantize_variant(int v) { g_quant_wg_per_cu = v > 0 ? v : 0; }
+void set_quantize_variant(int v) { g_quant_wg_per_cu.store(v > 0 ? v : 0, std::memory_order_relaxed); }
 }  // namespace fp4
 
 extern "C" int fp4_hip_quantize_blockwise(const void *w, int w_dtype, uint8_t *packed, float *absmax, int64_t n,
@@ -272,7 +273,8 @@ extern "C" int fp4_hip_quantize_blockwise(const void *w, int w_dtype, uint8_t *p
     const int64_t per_wg = int64_t(kQThreads) * 8;
     const int64_t ntiles = (n + per_wg - 1) / per_wg;
     // 4 workgroups of 512 threads fill a CU's 2048 wave slots; each keeps one tile in flight while it ranks another
-    const int wg_per_cu = g_quant_wg_per_cu ? g_quant_wg_per_cu : 4;
+    const int wg_override = g_quant_wg_per_cu.load(std::memory_order_relaxed);
+    const int wg_per_cu = wg_override ? wg_override : 4;
     const unsigned blocks = (unsigned)std::min<int64_t>(ntiles, int64_t(device_cu_count()) * wg_per_cu);  // ntiles >= 1
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch (w_dtype) {
