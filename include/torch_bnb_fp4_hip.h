@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FP4_HIP_ABI_VERSION 2
+#define FP4_HIP_ABI_VERSION 3
 #define FP4_HIP_API __attribute__((visibility("default")))
 
 /* Element types, numbered like the reference's ScalarTypeEnum (csrc/torch_fp4.cpp:22-26). */
@@ -90,6 +90,25 @@ FP4_HIP_API int fp4_hip_dequantize_blockwise(const uint8_t *packed, const float 
  */
 FP4_HIP_API int fp4_hip_gemv(const void *x, const uint8_t *packed, const float *absmax, const void *bias, void *out, int64_t M,
                  int64_t K, int blocksize, int dtype, void *stream);
+
+/*
+ * The same GEMV with the elementwise work that FOLLOWS a Linear in a decoder layer folded into its epilogue, so that a
+ * decode step pays one kernel boundary where the reference's op surface pays two to four
+ * (torch_bnb_fp4/__init__.py:603-613 is where the reference already pays a separate launch for the bias).
+ * Every intermediate is rounded to T exactly where the separate torch ops would round it:
+ *   EPILOGUE_NONE:            t = T(sum_r); if bias: t = T(t + bias[r]); if residual: t = T(t + residual[r]); out[r] = t
+ *                             out : T[M].  `residual` may alias `out` (h = h + Linear(a) in place).
+ *   EPILOGUE_SILU_MUL_PAIRS:  the weight's rows interleave a gate and an up projection (row 2i = gate_i, row 2i+1 = up_i;
+ *                             a row permutation done once at load time - rows of an FP4 weight are independent);
+ *                             g = T(sum_2i) (+bias), u = T(sum_2i+1) (+bias), s = T(g / (1 + exp(-g))) (torch's silu),
+ *                             t = T(s * u); if residual: t = T(t + residual[i]); out[i] = t.   out : T[M/2], M even.
+ * 16-bit dtypes with K % 32 == 0 and a power-of-two blocksize >= 32 dividing K (the decode fast path) support both
+ * epilogues; other shapes / f32 support EPILOGUE_NONE only and return FP4_ERR_UNSUPPORTED for the gated one, so the
+ * caller can run the plain GEMV and the separate ops.  Not in the reference.
+ */
+enum fp4_epilogue { FP4_EPILOGUE_NONE = 0, FP4_EPILOGUE_SILU_MUL_PAIRS = 1 };
+FP4_HIP_API int fp4_hip_gemv_fused(const void *x, const uint8_t *packed, const float *absmax, const void *bias, const void *residual,
+                       void *out, int64_t M, int64_t K, int blocksize, int dtype, int epilogue, void *stream);
 
 /*
  * Small-batch companion of the GEMV (2..64 activation rows; also accepts 1; one launch per 16 rows):

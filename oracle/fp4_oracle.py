@@ -284,6 +284,34 @@ QUANT_THRESHOLDS = np.array(
 RANK_TO_CODE = np.array([0b000, 0b001, 0b110, 0b111, 0b100, 0b101, 0b010, 0b011], dtype=np.uint8)
 
 
+def linear_epilogue(y, dtype: str, bias=None, residual=None) -> np.ndarray:
+    """What follows a GEMV in the reference and in the model code, one rounded op at a time: ``out = T(y)``, then the
+    in-place ``out += bias`` (torch_bnb_fp4/__init__.py:608-613), then the caller's ``h + out``; each is an f32 add
+    rounded to T (what torch does for 16-bit tensors).  y may be float64 (the exact sum) or already T-valued."""
+    rt = round_to(dtype)
+    t = rt(y)
+    if bias is not None:
+        t = rt(t.astype(np.float32) + np.asarray(bias, np.float32))
+    if residual is not None:
+        t = rt(t.astype(np.float32) + np.asarray(residual, np.float32))
+    return t
+
+
+def silu_mul_epilogue(gate, up, dtype: str, residual=None) -> np.ndarray:
+    """``silu(gate) * up`` as the model code runs it on T tensors (e.g. transformers' LlamaMLP ``act_fn(gate_proj(x)) *
+    up_proj(x)``): gate and up are T-valued; silu = x / (1 + exp(-x)) evaluated in f32 and rounded to T; the product is
+    rounded to T; an optional residual add is one more rounded op.  exp here is numpy's f32 exp, which may differ from the
+    device library's by an ulp of f32 - visible in the T result only when that lands on a rounding boundary."""
+    rt = round_to(dtype)
+    g = rt(gate).astype(np.float32)
+    u = rt(up).astype(np.float32)
+    s = rt(g / (np.float32(1.0) + np.exp(-g, dtype=np.float32)))
+    t = rt(s.astype(np.float32) * u)
+    if residual is not None:
+        t = rt(t.astype(np.float32) + np.asarray(residual, np.float32))
+    return t
+
+
 def quantize_fp4(w, blocksize: int = 64):
     """Blockwise FP4 quantisation of a flat float array.
 

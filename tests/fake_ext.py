@@ -54,6 +54,24 @@ class FakeExt:
         self.calls.append("gemv_fp4_bias")
         return self._gemv(A, B, absmax, blocksize, dtype, Bshape, bias)
 
+    def gemv_fp4_fused(self, A, B, absmax, blocksize, Bshape, bias, residual, epilogue):
+        self.calls.append("gemv_fp4_fused")
+        M, K = Bshape
+        if epilogue == 1 and (A.dtype == torch.float32 or K > 16384):
+            raise RuntimeError("fp4_hip_gemv_fused: the gate|up epilogue is not available for this shape")
+        assert A.is_contiguous() and A.numel() == K
+        y = o.gemv_exact(A.float().numpy().reshape(-1), B.numpy().reshape(-1), absmax.numpy(), M, K, blocksize)
+        nb = None if bias is None else bias.float().numpy()
+        nr = None if residual is None else residual.float().numpy().reshape(-1)
+        if A.dtype == torch.float32:
+            t = y.astype(np.float32) + (0 if nb is None else nb) + (0 if nr is None else nr)
+        elif epilogue == 1:
+            t = o.linear_epilogue(y, _NP[A.dtype], nb)
+            t = o.silu_mul_epilogue(t[0::2], t[1::2], _NP[A.dtype], nr)
+        else:
+            t = o.linear_epilogue(y, _NP[A.dtype], nb, nr)
+        return torch.from_numpy(np.asarray(t, np.float32)).to(A.dtype).view(*A.shape[:-1], -1)
+
     def gemm_small_fp4(self, A, B, absmax, blocksize, Bshape, bias):
         self.calls.append("gemm_small_fp4")
         M, K = Bshape

@@ -38,6 +38,8 @@ def lib():
         l.fp4_hip_dequantize_blockwise.argtypes = [vp, vp, vp, i32, i64, i32, i32, i32, vp]
         l.fp4_hip_gemv.argtypes = [vp, vp, vp, vp, vp, i64, i64, i32, i32, vp]
         l.fp4_hip_gemv_partial.argtypes = [vp, vp, vp, vp, i64, i64, i32, i32, vp]
+        l.fp4_hip_gemv_fused.argtypes = [vp, vp, vp, vp, vp, vp, i64, i64, i32, i32, i32, vp]
+        l.fp4_hip_gemv_fused.restype = i32
         l.fp4_hip_gemm_small.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, i32, i32, vp]
         l.fp4_hip_gemm_small.restype = i32
         l.fp4_hip_quantize_blockwise.argtypes = [vp, i32, vp, vp, i64, i32, vp]
@@ -79,6 +81,22 @@ def gemv(x: torch.Tensor, packed: torch.Tensor, absmax: torch.Tensor, M: int, K:
     rc = lib().fp4_hip_gemv(_ptr(x), _ptr(packed), _ptr(absmax), _ptr(bias), _ptr(out), M, K, blocksize, DT[x.dtype], _stream())
     assert rc == OK, (rc, last_error())
     return out
+
+
+EPILOGUE_NONE, EPILOGUE_SILU_MUL_PAIRS = 0, 1
+
+
+def gemv_fused(x: torch.Tensor, packed: torch.Tensor, absmax: torch.Tensor, M: int, K: int, blocksize: int,
+               bias: torch.Tensor | None = None, residual: torch.Tensor | None = None, epilogue: int = EPILOGUE_NONE,
+               out: torch.Tensor | None = None, expect_ok: bool = True):
+    if out is None:
+        out = torch.empty(M // 2 if epilogue == EPILOGUE_SILU_MUL_PAIRS else M, dtype=x.dtype, device=x.device)
+    rc = lib().fp4_hip_gemv_fused(_ptr(x), _ptr(packed), _ptr(absmax), _ptr(bias), _ptr(residual), _ptr(out), M, K, blocksize,
+                                  DT[x.dtype], epilogue, _stream())
+    if expect_ok:
+        assert rc == OK, (rc, last_error())
+        return out
+    return rc
 
 
 def gemm_small(x: torch.Tensor, packed: torch.Tensor, absmax: torch.Tensor, M: int, K: int, blocksize: int,

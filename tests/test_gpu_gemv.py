@@ -71,6 +71,27 @@ def test_golden_cases_and_reference_emulation(golden, tag, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,K", [(4096, 4096), (4096, 14336)])
+def test_bar2_reference_emulation_at_decode_shapes(dtype, M, K):
+    """Bar 2 at the headline shape and at the down-projection, default geometry: the kernel's mean |error| against the
+    float64 answer is no larger than that of an emulation of the REFERENCE kernel's arithmetic (T-rounded table and
+    absmax, T multiply, T accumulate per lane, f32 tree reduce: csrc/gemv_fp4_optimized.cu:87-156).  The kernel runs on
+    the full matrix; the (row-independent) emulation is evaluated on the first 512 rows to bound the test's run time."""
+    rows = 512
+    packed, am, x = make_case(M, K, seed=5 + K)
+    x_t = torch_values(x, dtype)
+    y = hipabi.gemv(x_t, to_dev(packed), to_dev(am), M, K, 64)
+    exact, err = check(y, x_t, packed, am, M, K, 64, dtype)  # bar 1 on every row
+    xv = x_t.float().cpu().numpy()
+    p_s, a_s = packed[: rows * K // 2], am[: rows * K // 64]
+    emu = o.gemv_reference_emulated(xv, p_s, a_s, rows, K, 64, NPDT[dtype]).astype(np.float64)
+    emu_err = np.abs(emu - exact[:rows])
+    assert err[:rows].mean() <= emu_err.mean() * 1.05 + 1e-12, (err[:rows].mean(), emu_err.mean())
+    # and the emulation itself stays within the reference's own accuracy class (a sanity check of the emulation)
+    assert emu_err.mean() <= 40 * HALF_ULP[dtype] * np.abs(exact[:rows]).mean() + 1e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("variant", VARIANTS16)
 def test_4096x4096_every_variant(dtype, variant):
     M = K = 4096

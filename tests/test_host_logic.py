@@ -145,6 +145,59 @@ def test_small_batch_opt_in(fake):
     assert fake.calls == ["gemv_fp4_bias"]
 
 
+def test_fused_layers_dispatch_and_fall_back(fake, monkeypatch):
+    """torch_bnb_fp4.fused on CPU (oracle-backed ops): row interleaving, the single-token fused call, the unfused fallback for
+    batches and for shapes the kernel reports as not covered, residual semantics."""
+    from torch_bnb_fp4 import fused
+
+    monkeypatch.setattr(fused, "ext", fake)
+    M, K = 32, 128
+    rng = np.random.default_rng(3)
+    wg, wu = ((rng.standard_normal(M * K) * 0.05).astype(np.float32) for _ in range(2))
+    (pg, ag), (pu, au) = o.quantize_fp4(wg, 64), o.quantize_fp4(wu, 64)
+    tg = (torch.from_numpy(pg).view(-1, 1), torch.from_numpy(ag))
+    tu = (torch.from_numpy(pu).view(-1, 1), torch.from_numpy(au))
+    packed, absmax, shape = fused.interleave_rows(tg, tu, (M, K), 64)
+    assert shape == (2 * M, K)
+    full = o.dequantize_f32(packed.numpy().reshape(-1), absmax.numpy(), 64, 2 * M * K).reshape(2 * M, K)
+    assert np.array_equal(full[0::2], o.dequantize_f32(pg, ag, 64, M * K).reshape(M, K))
+    assert np.array_equal(full[1::2], o.dequantize_f32(pu, au, 64, M * K).reshape(M, K))
+    with pytest.raises(ValueError):
+        fused.interleave_rows(tg, tu, (M, K + 64), 64)
+
+    monkeypatch.setattr(fused, "fp4_code", lambda: torch.from_numpy(o.TREE_TABLE.copy()))
+    gu = fused.FusedFP4Linear.gate_up_from_packed(tg, tu, (M, K), 64)
+    assert gu.out_features == M and gu.in_features == K
+    x = torch.randn(1, K).to(torch.bfloat16)
+    y = gu(x)
+    assert fake.calls == ["gemv_fp4_fused"] and y.shape == (1, M)
+    g64 = o.gemv_exact(x.float().numpy().reshape(-1), pg, ag, M, K, 64)
+    u64 = o.gemv_exact(x.float().numpy().reshape(-1), pu, au, M, K, 64)
+    want = o.silu_mul_epilogue(g64, u64, "bfloat16")
+    assert np.array_equal(y.float().numpy().reshape(-1), want)
+    # a batch runs the unfused sequence (de-interleaving the rows), same meaning
+    fake.calls.clear()
+    xb = torch.cat([x, x])
+    yb = gu(xb)
+    assert "gemv_fp4_fused" not in fake.calls and yb.shape == (2, M)
+    assert (yb[0].float() - y[0].float()).abs().max() <= 0.05 * max(1.0, y.float().abs().max().item())
+    # plain layer: residual in the epilogue for one token, added separately for a batch
+    dn = fused.FusedFP4Linear.from_packed(*tg, (M, K), 64)
+    r = torch.randn(1, M).to(torch.bfloat16)
+    fake.calls.clear()
+    z = dn(x, residual=r)
+    assert fake.calls == ["gemv_fp4_fused"]
+    assert np.array_equal(z.float().numpy().reshape(-1), o.linear_epilogue(g64, "bfloat16", None, r.float().numpy().reshape(-1)))
+    assert dn(xb, residual=torch.cat([r, r])).shape == (2, M)
+    # f32 activations: the kernel reports the gated epilogue as not available -> unfused from then on, no error
+    gu32 = fused.FusedFP4Linear.gate_up_from_packed(tg, tu, (M, K), 64)
+    fake.calls.clear()
+    y32 = gu32(x.float())
+    assert y32.shape == (1, M) and not gu32._fused_ok and fake.calls[0] == "gemv_fp4_fused" and "gemv_fp4" in fake.calls
+    with pytest.raises(ValueError):
+        fused.FusedFP4Linear(dn.quant_data, epilogue=5)
+
+
 def test_surgery_helpers_cpu():
     assert pkg.check_if_name_contained_in_list("model.lm_head", ["lm_head"])
     assert not pkg.check_if_name_contained_in_list("proj", ["lm_head", "pooler"])

@@ -121,6 +121,76 @@ __global__ __launch_bounds__(THREADS) void dq(const uint8_t *__restrict__ packed
     }
 }
 
+
+// Persistent variant (round 2, one bounded attempt): gridDim.x = k workgroups per CU, each walks tiles with stride
+// gridDim.x; the NEXT tile's packed words and scales are requested before the current tile is decoded and stored, so a
+// workgroup always has loads in flight behind its stores.  Scales are staged per wave (wave barrier only) into a
+// double-buffered LDS slice; the LUT is staged once.
+template <int LOADS, int THREADS>
+__global__ __launch_bounds__(THREADS) void dqp(const uint8_t *__restrict__ packed, const float *__restrict__ absmax,
+                                               void *__restrict__ out, int ntiles) {
+    constexpr int kVals = 8, bs_shift = 6;
+    constexpr int kTile = THREADS * LOADS * kVals;
+    constexpr int per_wave = 64 * LOADS * kVals / 64;  // scales per wave and tile
+    static_assert(per_wave <= 64, "one scale per lane at most");
+    __shared__ float s_lut[16];
+    __shared__ float s_abs[2][THREADS / 64][per_wave];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < 16) s_lut[tid] = lut_entry(tid);
+    __syncthreads();
+    auto issue = [&](int tile, uint32_t (&q)[LOADS], float &a) {
+        const int64_t e_base = int64_t(tile) * kTile;
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(packed) + (e_base / kVals) + wave * (64 * LOADS) + lane;
+#pragma unroll
+        for (int j = 0; j < LOADS; ++j) q[j] = __builtin_nontemporal_load(src + j * 64);
+        a = absmax[(e_base >> bs_shift) + wave * per_wave + (lane < per_wave ? lane : per_wave - 1)];
+    };
+    uint32_t qa[LOADS], qb[LOADS];
+    float aa, ab;
+    int tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    issue(tile, qa, aa);
+    int par = 0;
+    auto body = [&](int t, const uint32_t (&q)[LOADS], float a) {
+        if (lane < per_wave) s_abs[par][wave][lane] = a;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int64_t e_base = int64_t(t) * kTile;
+#pragma unroll
+        for (int j = 0; j < LOADS; ++j) {
+            const int wl = j * 64 + lane;  // word inside this wave's span
+            const float am = s_abs[par][wave][(wl * kVals) >> bs_shift];
+            float v[kVals];
+#pragma unroll
+            for (int i = 0; i < kVals; ++i) v[i] = s_lut[nibble_of(q[j], i)] * am;
+            u32x4 o = {pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
+            __builtin_nontemporal_store(o, reinterpret_cast<u32x4 *>(out) + (e_base + (wave * (64 * LOADS) + wl) * kVals) / 8);
+        }
+        par ^= 1;
+    };
+    while (true) {
+        int next = tile + gridDim.x;
+        if (next < ntiles) issue(next, qb, ab);
+        body(tile, qa, aa);
+        if (next >= ntiles) break;
+        tile = next;
+        next = tile + gridDim.x;
+        if (next < ntiles) issue(next, qa, aa);
+        body(tile, qb, ab);
+        if (next >= ntiles) break;
+        tile = next;
+    }
+}
+
+template <int LOADS, int THREADS, int WG_PER_CU>
+void launch_p(const uint8_t *p, const float *a, void *o, int64_t n, hipStream_t s) {
+    constexpr int tile = THREADS * LOADS * 8;
+    const int ntiles = (int)(n / tile);
+    const int grid = std::min(ntiles, WG_PER_CU * 256);
+    hipLaunchKernelGGL((dqp<LOADS, THREADS>), dim3(grid), dim3(THREADS), 0, s, p, a, o, ntiles);
+}
+
 struct Variant {
     const char *name;
     void (*launch)(const uint8_t *, const float *, void *, int64_t, hipStream_t);
@@ -156,6 +226,21 @@ int main(int argc, char **argv) {
     CK(hipStreamCreate(&s));
     // aux bits (gfx940+): 1 = sc0, 2 = nt, 16 = sc1
     std::vector<Variant> vs = {
+        {"PERSIST L4 T256 k=8 (one tile)", launch_p<4, 256, 8>},
+        {"PERSIST L4 T256 k=4       ", launch_p<4, 256, 4>},
+        {"PERSIST L4 T256 k=2       ", launch_p<4, 256, 2>},
+        {"PERSIST L2 T256 k=8       ", launch_p<2, 256, 8>},
+        {"PERSIST L2 T256 k=4       ", launch_p<2, 256, 4>},
+        {"PERSIST L2 T256 k=2       ", launch_p<2, 256, 2>},
+        {"PERSIST L1 T256 k=8       ", launch_p<1, 256, 8>},
+        {"PERSIST L1 T256 k=4       ", launch_p<1, 256, 4>},
+        {"PERSIST L4 T512 k=4       ", launch_p<4, 512, 4>},
+        {"PERSIST L4 T512 k=2       ", launch_p<4, 512, 2>},
+        {"PERSIST L2 T512 k=4       ", launch_p<2, 512, 4>},
+        {"PERSIST L2 T512 k=2       ", launch_p<2, 512, 2>},
+        {"PERSIST L2 T1024 k=2      ", launch_p<2, 1024, 2>},
+        {"PERSIST L2 T1024 k=1      ", launch_p<2, 1024, 1>},
+        {"PERSIST L1 T1024 k=2      ", launch_p<1, 1024, 2>},
         {"L4 T256 plain            ", launch<4, 256, 0, false, false, 0>},
         {"L4 T256 nt(builtin)      ", launch<4, 256, 2, false, false, 0>},
         {"L4 T256 buf aux0         ", launch<4, 256, 0, true, false, 0>},
@@ -221,6 +306,26 @@ int main(int argc, char **argv) {
         fflush(stdout);
         CK(hipGraphExecDestroy(ge));
         CK(hipGraphDestroy(g));
+    }
+    // persistent vs one-shot outputs, bit for bit (matrix 0): run one of each into two buffers and compare on the host
+    {
+        std::vector<uint16_t> ra(n), rb(n);
+        CK(hipMemset(outs[0], 0, n * 2));
+        CK(hipMemset(outs[1], 0, n * 2));
+        launch<4, 256, 2, false, true, 0>(packed[0], absmax[0], outs[0], n, s);
+        launch_p<2, 256, 2>(packed[0], absmax[0], outs[1], n, s);
+        CK(hipStreamSynchronize(s));
+        CK(hipMemcpy(ra.data(), outs[0], n * 2, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(rb.data(), outs[1], n * 2, hipMemcpyDeviceToHost));
+        size_t bad = 0;
+        for (int64_t i = 0; i < n; ++i) bad += ra[i] != rb[i];
+        printf("persistent L2 T256 k=2 vs one-shot L4 T256: %zu mismatching elements of %lld\n", bad, (long long)n);
+        launch_p<4, 512, 2>(packed[0], absmax[0], outs[1], n, s);
+        CK(hipStreamSynchronize(s));
+        CK(hipMemcpy(rb.data(), outs[1], n * 2, hipMemcpyDeviceToHost));
+        bad = 0;
+        for (int64_t i = 0; i < n; ++i) bad += ra[i] != rb[i];
+        printf("persistent L4 T512 k=2 vs one-shot L4 T256: %zu mismatching elements of %lld\n", bad, (long long)n);
     }
     // sanity: last variant's output of matrix 0, element checks on the host
     std::vector<uint16_t> ho(1024);

@@ -68,16 +68,42 @@ __device__ __forceinline__ float wave_sum(float v) {
     return a + b;
 }
 
+// bit flags of the 16-bit GEMV kernels' `mode` argument
+constexpr int kModeOutF32 = 1;        // K-split partial: the raw f32 accumulator goes out, summed across shards before any rounding
+constexpr int kModeSiluMulPairs = 2;  // rows (2i, 2i+1) hold (gate_i, up_i): out[i] = silu(gate_i) * up_i  (fp4_hip_gemv_fused)
+
+// Row epilogue.  Every step rounds to T exactly where the reference's separate torch ops would:
+//   out = T(gemv); out += bias (torch_bnb_fp4/__init__.py:608-613); then the caller's `h + out` as one more rounded add.
+// `residual` may alias `out` (the row is read before it is written, by the same lane).
 template <int DT>
-__device__ __forceinline__ void store_row(uint16_t *out, const uint16_t *bias, int row, float sum, int out_f32 = 0) {
-    if (out_f32) {  // K-split partial: the raw f32 accumulator, summed across shards before any rounding
+__device__ __forceinline__ void store_row(uint16_t *out, const uint16_t *bias, const uint16_t *residual, int row, float sum,
+                                          int mode = 0) {
+    if (mode & kModeOutF32) {
         reinterpret_cast<float *>(out)[row] = sum;
         return;
     }
     uint16_t t = from_f32<DT>(sum);
-    // reference: out = T(gemv); out += bias  (torch_bnb_fp4/__init__.py:608-613) -> two roundings
     if (bias) t = from_f32<DT>(to_f32<DT>(t) + to_f32<DT>(bias[row]));
+    if (residual) t = from_f32<DT>(to_f32<DT>(t) + to_f32<DT>(residual[row]));
     out[row] = t;
+}
+
+// Gated-MLP epilogue for a weight whose rows interleave the gate and the up projection: what the model code does with
+// three more launches - g = gate(h), u = up(h) (each rounded to T, bias added as above), silu(g) (torch: x / (1 + exp(-x)) in
+// f32, rounded to T), then the product rounded to T - and optionally the residual add on top.
+template <int DT>
+__device__ __forceinline__ void store_silu_mul(uint16_t *out, const uint16_t *bias, const uint16_t *residual, int pair,
+                                               float gate_sum, float up_sum) {
+    uint16_t g = from_f32<DT>(gate_sum), u = from_f32<DT>(up_sum);
+    if (bias) {
+        g = from_f32<DT>(to_f32<DT>(g) + to_f32<DT>(bias[2 * pair]));
+        u = from_f32<DT>(to_f32<DT>(u) + to_f32<DT>(bias[2 * pair + 1]));
+    }
+    const float gf = to_f32<DT>(g);
+    const uint16_t s = from_f32<DT>(gf / (1.0f + expf(-gf)));
+    uint16_t t = from_f32<DT>(to_f32<DT>(s) * to_f32<DT>(u));
+    if (residual) t = from_f32<DT>(to_f32<DT>(t) + to_f32<DT>(residual[pair]));
+    out[pair] = t;
 }
 
 }  // namespace

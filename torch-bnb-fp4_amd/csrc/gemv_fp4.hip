@@ -98,8 +98,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemv16_kernel(const uint16_t *__re
                                                             const uint8_t *__restrict__ W,
                                                             const float *__restrict__ absmax,
                                                             const uint16_t *__restrict__ bias,
-                                                            uint16_t *__restrict__ out, int M, int K, int bs_shift,
-                                                            int out_f32) {
+                                                            const uint16_t *residual, uint16_t *out, int M, int K,
+                                                            int bs_shift, int mode) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_x[];
     u32x4 *s_x4 = reinterpret_cast<u32x4 *>(s_x);
     const int tid = threadIdx.x;
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv16_kernel(const uint16_t *__re
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
         const float total = wave_sum(acc[r]) * (1.0f / 12.0f);
-        if (lane == 0 && row0 + r < M) store_row<DT>(out, bias, row0 + r, total, out_f32);
+        if (lane == 0 && row0 + r < M) store_row<DT>(out, bias, residual, row0 + r, total, mode);
     }
 }
 
@@ -181,8 +181,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemv16_kernel(const uint16_t *__re
 template <int DT, int KSPLIT, int G, int ITERS, int WAVES = 4>
 __global__ __launch_bounds__(WAVES * 64, (G >= 4 ? 4 : 1)) void gemv16_regx_kernel(const uint16_t *__restrict__ x, const uint8_t *__restrict__ W,
                                                           const float *__restrict__ absmax,
-                                                          const uint16_t *__restrict__ bias, uint16_t *__restrict__ out,
-                                                          int M, int K, int bs_shift, int out_f32) {
+                                                          const uint16_t *__restrict__ bias, const uint16_t *residual,
+                                                          uint16_t *out, int M, int K, int bs_shift, int mode) {
     constexpr int RG = WAVES / KSPLIT;           // row-pair groups per workgroup
     constexpr int kRowsPerBlock = 2 * RG * ITERS;
     __shared__ float s_part[kRowsPerBlock][KSPLIT];
@@ -326,19 +326,33 @@ __global__ __launch_bounds__(WAVES * 64, (G >= 4 ? 4 : 1)) void gemv16_regx_kern
         p += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, p), 0x401F));
         if constexpr (KSPLIT == 1) {
             const int row = row_base + rowi[it];
-            if (l32 == 0 && row < M) store_row<DT>(out, bias, row, p * (1.0f / 12.0f), out_f32);
+            if (mode & kModeSiluMulPairs) {
+                // the two half-waves hold the gate row (even, lanes 0..31) and the up row (odd) of one pair; M is even
+                const float up = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, p), 32));
+                if (lane == 0 && row < M) store_silu_mul<DT>(out, bias, residual, row >> 1, p * (1.0f / 12.0f), up * (1.0f / 12.0f));
+            } else if (l32 == 0 && row < M) {
+                store_row<DT>(out, bias, residual, row, p * (1.0f / 12.0f), mode);
+            }
         } else {
             if (l32 == 0) s_part[rowi[it]][kw] = p;
         }
     }
     if constexpr (KSPLIT > 1) {
         __syncthreads();
-        if (tid < kRowsPerBlock) {
+        if (mode & kModeSiluMulPairs) {
+            if (tid < kRowsPerBlock / 2) {  // rows 2*tid (gate) and 2*tid + 1 (up) of this workgroup; row_base and M are even
+                float g = 0.0f, u = 0.0f;
+#pragma unroll
+                for (int k = 0; k < KSPLIT; ++k) g += s_part[2 * tid][k], u += s_part[2 * tid + 1][k];
+                const int row = row_base + 2 * tid;
+                if (row < M) store_silu_mul<DT>(out, bias, residual, row >> 1, g * (1.0f / 12.0f), u * (1.0f / 12.0f));
+            }
+        } else if (tid < kRowsPerBlock) {
             float t = 0.0f;
 #pragma unroll
             for (int k = 0; k < KSPLIT; ++k) t += s_part[tid][k];
             const int row = row_base + tid;
-            if (row < M) store_row<DT>(out, bias, row, t * (1.0f / 12.0f), out_f32);
+            if (row < M) store_row<DT>(out, bias, residual, row, t * (1.0f / 12.0f), mode);
         }
     }
 }
@@ -348,8 +362,8 @@ __global__ __launch_bounds__(WAVES * 64, (G >= 4 ? 4 : 1)) void gemv16_regx_kern
 template <int ROWS, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void gemv32_kernel(const float *__restrict__ x, const uint8_t *__restrict__ W,
                                                             const float *__restrict__ absmax,
-                                                            const float *__restrict__ bias, float *__restrict__ out, int M,
-                                                            int K, int bs_shift) {
+                                                            const float *__restrict__ bias, const float *residual, float *out,
+                                                            int M, int K, int bs_shift) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_raw[];
     f32x4 *s_x4 = reinterpret_cast<f32x4 *>(s_raw);
     __shared__ float s_lut[16];
@@ -403,7 +417,10 @@ __global__ __launch_bounds__(WAVES * 64) void gemv32_kernel(const float *__restr
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
         const float total = wave_sum(acc[r]);
-        if (lane == 0 && row0 + r < M) out[row0 + r] = bias ? total + bias[row0 + r] : total;
+        if (lane == 0 && row0 + r < M) {
+            const float t = bias ? total + bias[row0 + r] : total;
+            out[row0 + r] = residual ? t + residual[row0 + r] : t;
+        }
     }
 }
 
@@ -413,7 +430,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv32_kernel(const float *__restr
 template <int KSPLIT, int G, int ITERS, bool PERM>
 __global__ __launch_bounds__(256) void gemv32_regx_kernel(const float *__restrict__ x, const uint8_t *__restrict__ W,
                                                           const float *__restrict__ absmax, const float *__restrict__ bias,
-                                                          float *__restrict__ out, int M, int K, int bs_shift) {
+                                                          const float *residual, float *out, int M, int K, int bs_shift) {
     constexpr int RG = 4 / KSPLIT;
     constexpr int kRowsPerBlock = 2 * RG * ITERS;
     __shared__ float s_lut[16];
@@ -503,7 +520,10 @@ __global__ __launch_bounds__(256) void gemv32_regx_kernel(const float *__restric
         p += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, p), 0x401F));
         if constexpr (KSPLIT == 1) {
             const int row = row_base + rowi[it];
-            if (l32 == 0 && row < M) out[row] = bias ? p + bias[row] : p;
+            if (l32 == 0 && row < M) {
+                const float t = bias ? p + bias[row] : p;
+                out[row] = residual ? t + residual[row] : t;
+            }
         } else {
             if (l32 == 0) s_part[rowi[it]][kw] = p;
         }
@@ -515,25 +535,28 @@ __global__ __launch_bounds__(256) void gemv32_regx_kernel(const float *__restric
 #pragma unroll
             for (int k = 0; k < KSPLIT; ++k) t += s_part[tid][k];
             const int row = row_base + tid;
-            if (row < M) out[row] = bias ? t + bias[row] : t;
+            if (row < M) {
+                t = bias ? t + bias[row] : t;
+                out[row] = residual ? t + residual[row] : t;
+            }
         }
     }
 }
 
 template <int KSPLIT, int G, int ITERS, bool PERM>
-int launch32_regx(const void *x, const uint8_t *W, const float *absmax, const void *bias, void *out, int M, int K, int bs_shift,
-                  hipStream_t stream) {
+int launch32_regx(const void *x, const uint8_t *W, const float *absmax, const void *bias, const void *residual, void *out, int M,
+                  int K, int bs_shift, hipStream_t stream) {
     constexpr int rows_per_block = 2 * (4 / KSPLIT) * ITERS;
     const unsigned blocks = (unsigned)((M + rows_per_block - 1) / rows_per_block);
     hipLaunchKernelGGL((gemv32_regx_kernel<KSPLIT, G, ITERS, PERM>), dim3(blocks), dim3(256), 0, stream,
                        reinterpret_cast<const float *>(x), W, absmax, reinterpret_cast<const float *>(bias),
-                       reinterpret_cast<float *>(out), M, K, bs_shift);
+                       reinterpret_cast<const float *>(residual), reinterpret_cast<float *>(out), M, K, bs_shift);
     return FP4_OK;
 }
 
 // returns -1 when K is too deep for a register-resident f32 x slice (K > 8192): use the LDS kernel
-int dispatch32_regx(bool perm, int iters, const void *x, const uint8_t *W, const float *absmax, const void *bias, void *out, int M,
-                    int K, int bs_shift, hipStream_t stream) {
+int dispatch32_regx(bool perm, int iters, const void *x, const uint8_t *W, const float *absmax, const void *bias,
+                    const void *residual, void *out, int M, int K, int bs_shift, hipStream_t stream) {
     const int C = K >> 5;
     const int ks = C <= 32 ? 1 : (C <= 64 ? 2 : 4);
     if (iters <= 0) {
@@ -545,12 +568,12 @@ int dispatch32_regx(bool perm, int iters, const void *x, const uint8_t *W, const
     }
 #define FP4_R32_IT(KS, GG, PERM)                                                                               \
     switch (iters) {                                                                                           \
-        case 1: return launch32_regx<KS, GG, 1, PERM>(x, W, absmax, bias, out, M, K, bs_shift, stream);        \
-        case 2: return launch32_regx<KS, GG, 2, PERM>(x, W, absmax, bias, out, M, K, bs_shift, stream);        \
-        case 4: return launch32_regx<KS, GG, 4, PERM>(x, W, absmax, bias, out, M, K, bs_shift, stream);        \
+        case 1: return launch32_regx<KS, GG, 1, PERM>(x, W, absmax, bias, residual, out, M, K, bs_shift, stream);        \
+        case 2: return launch32_regx<KS, GG, 2, PERM>(x, W, absmax, bias, residual, out, M, K, bs_shift, stream);        \
+        case 4: return launch32_regx<KS, GG, 4, PERM>(x, W, absmax, bias, residual, out, M, K, bs_shift, stream);        \
         default:                                                                                               \
-            if constexpr ((GG) == 1) return launch32_regx<KS, GG, 8, PERM>(x, W, absmax, bias, out, M, K, bs_shift, stream); \
-            return launch32_regx<KS, GG, 4, PERM>(x, W, absmax, bias, out, M, K, bs_shift, stream);            \
+            if constexpr ((GG) == 1) return launch32_regx<KS, GG, 8, PERM>(x, W, absmax, bias, residual, out, M, K, bs_shift, stream); \
+            return launch32_regx<KS, GG, 4, PERM>(x, W, absmax, bias, residual, out, M, K, bs_shift, stream);            \
     }
 #define FP4_R32(KS, GG)          \
     if (perm) {                  \
@@ -571,8 +594,8 @@ int dispatch32_regx(bool perm, int iters, const void *x, const uint8_t *W, const
 template <int DT>
 __global__ __launch_bounds__(256) void gemv_generic_kernel(const void *__restrict__ xv, const uint8_t *__restrict__ W,
                                                            const float *__restrict__ absmax, const void *__restrict__ biasv,
-                                                           void *__restrict__ outv, int M, int64_t K, int blocksize,
-                                                           CodeTable tbl, int out_f32) {
+                                                           const void *residualv, void *outv, int M, int64_t K, int blocksize,
+                                                           CodeTable tbl, int mode) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
@@ -596,10 +619,12 @@ __global__ __launch_bounds__(256) void gemv_generic_kernel(const void *__restric
     const float total = wave_sum(acc);
     if (lane == 0) {
         if constexpr (DT == FP4_DTYPE_F32) {
-            const float *bias = reinterpret_cast<const float *>(biasv);
-            reinterpret_cast<float *>(outv)[row] = bias ? total + bias[row] : total;
+            const float *bias = reinterpret_cast<const float *>(biasv), *residual = reinterpret_cast<const float *>(residualv);
+            const float t = bias ? total + bias[row] : total;
+            reinterpret_cast<float *>(outv)[row] = residual ? t + residual[row] : t;
         } else {
-            store_row<DT>(reinterpret_cast<uint16_t *>(outv), reinterpret_cast<const uint16_t *>(biasv), row, total, out_f32);
+            store_row<DT>(reinterpret_cast<uint16_t *>(outv), reinterpret_cast<const uint16_t *>(biasv),
+                          reinterpret_cast<const uint16_t *>(residualv), row, total, mode);
         }
     }
 }
@@ -622,26 +647,38 @@ int ensure_lds(Kern kern, size_t lds_bytes) {
     return FP4_OK;
 }
 
+// one 16-bit GEMV launch: operands, epilogue inputs and the mode flags of gemv_common.h
+struct GemvArgs {
+    const void *x;
+    const uint8_t *W;
+    const float *absmax;
+    const void *bias, *residual;
+    void *out;
+    int M, K, bs_shift, mode;
+    hipStream_t stream;
+};
+
 template <int DT, int ROWS, int WAVES, int UNROLL>
-int launch16(const void *x, const uint8_t *W, const float *absmax, const void *bias, void *out, int M, int K, int bs_shift,
-             int out_f32, hipStream_t stream) {
+int launch16(const GemvArgs &a) {
+    if (a.mode & kModeSiluMulPairs) return -2;  // a pair's rows sit in different waves here
     auto kern = gemv16_kernel<DT, ROWS, WAVES, UNROLL>;
+    const int M = a.M, K = a.K;
     const size_t lds = size_t(K) * 2;
     if (int rc = ensure_lds(kern, lds)) return rc;
     const int rows_per_block = ROWS * WAVES;
     const unsigned blocks = (unsigned)((M + rows_per_block - 1) / rows_per_block);
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(WAVES * 64), lds, stream, reinterpret_cast<const uint16_t *>(x), W, absmax,
-                       reinterpret_cast<const uint16_t *>(bias), reinterpret_cast<uint16_t *>(out), M, K, bs_shift, out_f32);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(WAVES * 64), lds, a.stream, reinterpret_cast<const uint16_t *>(a.x), a.W, a.absmax,
+                       reinterpret_cast<const uint16_t *>(a.bias), reinterpret_cast<const uint16_t *>(a.residual),
+                       reinterpret_cast<uint16_t *>(a.out), M, K, a.bs_shift, a.mode);
     return FP4_OK;
 }
 
 template <int DT>
-int dispatch16(int variant, const void *x, const uint8_t *W, const float *absmax, const void *bias, void *out, int M, int K,
-               int bs_shift, int out_f32, hipStream_t stream) {
+int dispatch16(int variant, const GemvArgs &a) {
     switch (variant) {
 #define FP4_V(R, Wv, U)                  \
     case (R | (Wv << 8) | (U << 16)):    \
-        return launch16<DT, R, Wv, U>(x, W, absmax, bias, out, M, K, bs_shift, out_f32, stream);
+        return launch16<DT, R, Wv, U>(a);
         FP4_V(1, 4, 1) FP4_V(1, 4, 2) FP4_V(2, 4, 2) FP4_V(1, 8, 2) FP4_V(2, 8, 2) FP4_V(1, 16, 2)
 #undef FP4_V
         default:
@@ -653,26 +690,25 @@ int dispatch16(int variant, const void *x, const uint8_t *W, const float *absmax
 constexpr int kRegxFlag = 1 << 24;
 
 template <int DT, int KSPLIT, int G, int ITERS, int WAVES = 4>
-int launch_regx(const void *x, const uint8_t *W, const float *absmax, const void *bias, void *out, int M, int K, int bs_shift,
-                int out_f32, hipStream_t stream) {
+int launch_regx(const GemvArgs &a) {
     constexpr int rows_per_block = 2 * (WAVES / KSPLIT) * ITERS;
-    const unsigned blocks = (unsigned)((M + rows_per_block - 1) / rows_per_block);
-    hipLaunchKernelGGL((gemv16_regx_kernel<DT, KSPLIT, G, ITERS, WAVES>), dim3(blocks), dim3(WAVES * 64), 0, stream,
-                       reinterpret_cast<const uint16_t *>(x), W, absmax, reinterpret_cast<const uint16_t *>(bias),
-                       reinterpret_cast<uint16_t *>(out), M, K, bs_shift, out_f32);
+    const unsigned blocks = (unsigned)((a.M + rows_per_block - 1) / rows_per_block);
+    hipLaunchKernelGGL((gemv16_regx_kernel<DT, KSPLIT, G, ITERS, WAVES>), dim3(blocks), dim3(WAVES * 64), 0, a.stream,
+                       reinterpret_cast<const uint16_t *>(a.x), a.W, a.absmax, reinterpret_cast<const uint16_t *>(a.bias),
+                       reinterpret_cast<const uint16_t *>(a.residual), reinterpret_cast<uint16_t *>(a.out), a.M, a.K, a.bs_shift,
+                       a.mode);
     return FP4_OK;
 }
 
 // K decides the band split and the x-slice depth; ITERS (row pairs per group) is the tunable.  `ks_override`
 // (sweeps only) forces KSPLIT; G follows from ceil(C / (32 * KSPLIT)).
 template <int DT>
-int dispatch_regx(int iters, int ks_override, const void *x, const uint8_t *W, const float *absmax, const void *bias, void *out,
-                  int M, int K, int bs_shift, int out_f32, hipStream_t stream) {
-    const int C = K >> 5;
+int dispatch_regx(int iters, int ks_override, const GemvArgs &a) {
+    const int C = a.K >> 5;
     if (ks_override == 8 && C > 64 && C <= 128) {  // sweep hook: 8 waves per workgroup (two row-pair groups)
-        if (iters == 1) return launch_regx<DT, 4, 1, 1, 8>(x, W, absmax, bias, out, M, K, bs_shift, out_f32, stream);
-        if (iters == 2) return launch_regx<DT, 4, 1, 2, 8>(x, W, absmax, bias, out, M, K, bs_shift, out_f32, stream);
-        if (iters == 4) return launch_regx<DT, 4, 1, 4, 8>(x, W, absmax, bias, out, M, K, bs_shift, out_f32, stream);
+        if (iters == 1) return launch_regx<DT, 4, 1, 1, 8>(a);
+        if (iters == 2) return launch_regx<DT, 4, 1, 2, 8>(a);
+        if (iters == 4) return launch_regx<DT, 4, 1, 4, 8>(a);
     }
     // K = 7 * 1024 * {1, 2, 4} (7168, 14336, 28672 - the Llama-3 / Mistral intermediate sizes): seven waves split the row into
     // seven bands, so no lane of a 32-chunk band is idle (4 bands leave an eighth of the deepest slice dead at 14336) and
@@ -680,18 +716,18 @@ int dispatch_regx(int iters, int ks_override, const void *x, const uint8_t *W, c
     if (ks_override == 7 && C % 224 == 0 && (C / 224 == 1 || C / 224 == 2 || C / 224 == 4)) {
         const int g7 = C / 224;
         if (g7 == 4 && iters > 2) iters = 2;
-        if (iters > 4) iters = 4;
+        if (iters > 4) iters = 4;  // (8 row pairs per workgroup measured slower: 9.8 vs 9.0 us at 4096 x 14336, profiles/r02_gemv_regx_sweep.txt)
 #define FP4_RX7(GG)                                                                                                   \
     switch (iters) {                                                                                                  \
-        case 1: return launch_regx<DT, 7, GG, 1, 7>(x, W, absmax, bias, out, M, K, bs_shift, out_f32, stream);        \
-        case 2: return launch_regx<DT, 7, GG, 2, 7>(x, W, absmax, bias, out, M, K, bs_shift, out_f32, stream);        \
-        default: return launch_regx<DT, 7, GG, 4, 7>(x, W, absmax, bias, out, M, K, bs_shift, out_f32, stream);       \
+        case 1: return launch_regx<DT, 7, GG, 1, 7>(a);        \
+        case 2: return launch_regx<DT, 7, GG, 2, 7>(a);        \
+        default: return launch_regx<DT, 7, GG, 4, 7>(a);       \
     }
         if (g7 == 1) { FP4_RX7(1) }
         if (g7 == 2) { FP4_RX7(2) }
         switch (iters) {
-            case 1: return launch_regx<DT, 7, 4, 1, 7>(x, W, absmax, bias, out, M, K, bs_shift, out_f32, stream);
-            default: return launch_regx<DT, 7, 4, 2, 7>(x, W, absmax, bias, out, M, K, bs_shift, out_f32, stream);
+            case 1: return launch_regx<DT, 7, 4, 1, 7>(a);
+            default: return launch_regx<DT, 7, 4, 2, 7>(a);
         }
 #undef FP4_RX7
     }
@@ -701,9 +737,9 @@ int dispatch_regx(int iters, int ks_override, const void *x, const uint8_t *W, c
         if (iters > 4) iters = 4;
 #define FP4_RXN(KS, GG)                                                                                               \
     switch (iters) {                                                                                                  \
-        case 1: return launch_regx<DT, KS, GG, 1, KS>(x, W, absmax, bias, out, M, K, bs_shift, out_f32, stream);      \
-        case 2: return launch_regx<DT, KS, GG, 2, KS>(x, W, absmax, bias, out, M, K, bs_shift, out_f32, stream);      \
-        default: return launch_regx<DT, KS, GG, 4, KS>(x, W, absmax, bias, out, M, K, bs_shift, out_f32, stream);     \
+        case 1: return launch_regx<DT, KS, GG, 1, KS>(a);      \
+        case 2: return launch_regx<DT, KS, GG, 2, KS>(a);      \
+        default: return launch_regx<DT, KS, GG, 4, KS>(a);     \
     }
         if (ks_override == 5 && gg == 1) { FP4_RXN(5, 1) }
         if (ks_override == 5 && gg == 2) { FP4_RXN(5, 2) }
@@ -714,16 +750,16 @@ int dispatch_regx(int iters, int ks_override, const void *x, const uint8_t *W, c
     if (ks_override == 8 && C > 128) {  // K split 8 ways over 8 waves: the default for K = 8192, a sweep hook elsewhere
         const int need8 = (C + 255) / 256;
         if (need8 <= 1) {
-            if (iters == 1) return launch_regx<DT, 8, 1, 1, 8>(x, W, absmax, bias, out, M, K, bs_shift, out_f32, stream);
-            if (iters == 2) return launch_regx<DT, 8, 1, 2, 8>(x, W, absmax, bias, out, M, K, bs_shift, out_f32, stream);
-            return launch_regx<DT, 8, 1, 4, 8>(x, W, absmax, bias, out, M, K, bs_shift, out_f32, stream);
+            if (iters == 1) return launch_regx<DT, 8, 1, 1, 8>(a);
+            if (iters == 2) return launch_regx<DT, 8, 1, 2, 8>(a);
+            return launch_regx<DT, 8, 1, 4, 8>(a);
         } else if (need8 <= 2) {
-            if (iters == 1) return launch_regx<DT, 8, 2, 1, 8>(x, W, absmax, bias, out, M, K, bs_shift, out_f32, stream);
-            if (iters == 2) return launch_regx<DT, 8, 2, 2, 8>(x, W, absmax, bias, out, M, K, bs_shift, out_f32, stream);
-            return launch_regx<DT, 8, 2, 4, 8>(x, W, absmax, bias, out, M, K, bs_shift, out_f32, stream);
+            if (iters == 1) return launch_regx<DT, 8, 2, 1, 8>(a);
+            if (iters == 2) return launch_regx<DT, 8, 2, 2, 8>(a);
+            return launch_regx<DT, 8, 2, 4, 8>(a);
         } else if (need8 <= 4) {
-            if (iters == 1) return launch_regx<DT, 8, 4, 1, 8>(x, W, absmax, bias, out, M, K, bs_shift, out_f32, stream);
-            return launch_regx<DT, 8, 4, 2, 8>(x, W, absmax, bias, out, M, K, bs_shift, out_f32, stream);
+            if (iters == 1) return launch_regx<DT, 8, 4, 1, 8>(a);
+            return launch_regx<DT, 8, 4, 2, 8>(a);
         }
         return -1;
     }
@@ -735,7 +771,7 @@ int dispatch_regx(int iters, int ks_override, const void *x, const uint8_t *W, c
     if (g == 0) return -1;  // the x slice no longer fits the register budget; use the LDS geometry
     if (g == 2 && iters > 4) iters = 4;
     if (g >= 3 && iters > 2) iters = 2;
-#define FP4_RX(KS, GG, IT) return launch_regx<DT, KS, GG, IT>(x, W, absmax, bias, out, M, K, bs_shift, out_f32, stream)
+#define FP4_RX(KS, GG, IT) return launch_regx<DT, KS, GG, IT>(a)
     // only the (G, ITERS) pairs the clamps above let through are instantiated: G = 1 -> 1, 2, 4, 8; G = 2 -> 1, 2, 4; G >= 3 -> 1, 2
 #define FP4_RX_IT(KS, GG)                                    \
     if (ks == KS && g == GG) {                               \
@@ -791,11 +827,11 @@ int default_variant16(int M, int K) {
 }
 
 template <int DT>
-int run_generic(const void *x, const uint8_t *W, const float *absmax, const void *bias, void *out, int64_t M, int64_t K,
-                int blocksize, int out_f32, hipStream_t stream) {
+int run_generic(const void *x, const uint8_t *W, const float *absmax, const void *bias, const void *residual, void *out, int64_t M,
+                int64_t K, int blocksize, int mode, hipStream_t stream) {
     const CodeTable tbl = make_table(FP4_TABLE_CODEBOOK);
     hipLaunchKernelGGL((gemv_generic_kernel<DT>), dim3((unsigned)((M + 3) / 4)), dim3(256), 0, stream, x, W, absmax, bias,
-                       out, (int)M, K, blocksize, tbl, out_f32);
+                       residual, out, (int)M, K, blocksize, tbl, mode);
     return FP4_OK;
 }
 
@@ -807,8 +843,8 @@ void set_gemv_variant(int v) { g_gemv_variant.store(v, std::memory_order_relaxed
 
 namespace fp4 {
 namespace {
-int gemv_entry(const void *x, const uint8_t *packed, const float *absmax, const void *bias, void *out, int64_t M, int64_t K,
-               int blocksize, int dtype, int out_f32, void *stream) {
+int gemv_entry(const void *x, const uint8_t *packed, const float *absmax, const void *bias, const void *residual, void *out,
+               int64_t M, int64_t K, int blocksize, int dtype, int mode, void *stream) {
     if (M < 0 || K < 0 || (K & 1) || blocksize < 2 || (blocksize & 1)) {
         set_error("fp4_hip_gemv: M=%lld K=%lld blocksize=%d (need M,K >= 0, even K, even blocksize >= 2)", (long long)M,
                   (long long)K, blocksize);
@@ -818,6 +854,10 @@ int gemv_entry(const void *x, const uint8_t *packed, const float *absmax, const 
         // reference: std::runtime_error("Unsupported datatype") (csrc/gemv_fp4_optimized.cu:362-363)
         set_error("fp4_hip_gemv: unsupported dtype %d", dtype);
         return FP4_ERR_UNSUPPORTED;
+    }
+    if ((mode & kModeSiluMulPairs) && (M & 1)) {
+        set_error("fp4_hip_gemv_fused: the gate|up epilogue needs an even row count, got M=%lld", (long long)M);
+        return FP4_ERR_INVALID_ARGUMENT;
     }
     if (M == 0) return FP4_OK;
     if (!out || (K > 0 && (!x || !packed || !absmax))) {
@@ -837,25 +877,23 @@ int gemv_entry(const void *x, const uint8_t *packed, const float *absmax, const 
     int rc = FP4_OK;
     const int gv = g_gemv_variant.load(std::memory_order_relaxed);  // one snapshot per call
     if (fast && dtype != FP4_DTYPE_F32) {
+        const GemvArgs a{x, packed, absmax, bias, residual, out, (int)M, (int)K, bs_shift, mode, s};
         int variant = gv >= 0 ? gv : default_variant16((int)M, (int)K);
         rc = -1;
         if (variant & kRegxFlag) {
             const int iters = variant & 0xFF, ks_override = (variant >> 8) & 0xF;
-            rc = dtype == FP4_DTYPE_F16 ? dispatch_regx<FP4_DTYPE_F16>(iters, ks_override, x, packed, absmax, bias, out, (int)M,
-                                                                       (int)K, bs_shift, out_f32, s)
-                                        : dispatch_regx<FP4_DTYPE_BF16>(iters, ks_override, x, packed, absmax, bias, out, (int)M,
-                                                                        (int)K, bs_shift, out_f32, s);
+            rc = dtype == FP4_DTYPE_F16 ? dispatch_regx<FP4_DTYPE_F16>(iters, ks_override, a)
+                                        : dispatch_regx<FP4_DTYPE_BF16>(iters, ks_override, a);
             if (rc == -1) variant = 1 | (8 << 8) | (2 << 16);  // K too large for register-resident x
         }
-        if (rc == -1)
-            rc = dtype == FP4_DTYPE_F16
-                     ? dispatch16<FP4_DTYPE_F16>(variant, x, packed, absmax, bias, out, (int)M, (int)K, bs_shift, out_f32, s)
-                     : dispatch16<FP4_DTYPE_BF16>(variant, x, packed, absmax, bias, out, (int)M, (int)K, bs_shift, out_f32, s);
+        if (rc == -1) rc = dtype == FP4_DTYPE_F16 ? dispatch16<FP4_DTYPE_F16>(variant, a) : dispatch16<FP4_DTYPE_BF16>(variant, a);
+    } else if (mode & kModeSiluMulPairs) {
+        rc = -2;  // f32 activations / irregular shapes: only the register-x geometry pairs rows up
     } else if (fast && gv != 0 &&
                // default: the bit-faithful CODE_PARAM f32 table (the all-f32 reference kernel is accurate to ~1e-7, so the
                // table's 1e-6 deviations from k/12 are visible at f32); variant bit 8 selects the table-free decode (+10 %)
-               dispatch32_regx(gv >= 0 && ((gv >> 8) & 1), gv < 0 ? 0 : (gv & 0xFF), x,
-                               packed, absmax, bias, out, (int)M, (int)K, bs_shift, s) == FP4_OK) {
+               dispatch32_regx(gv >= 0 && ((gv >> 8) & 1), gv < 0 ? 0 : (gv & 0xFF), x, packed, absmax, bias, residual, out, (int)M,
+                               (int)K, bs_shift, s) == FP4_OK) {
         rc = FP4_OK;  // f32 activations, register-x geometry (variant 0 forces the LDS kernel below, for sweeps)
     } else if (fast) {
         auto kern = gemv32_kernel<1, 4>;
@@ -863,20 +901,26 @@ int gemv_entry(const void *x, const uint8_t *packed, const float *absmax, const 
         rc = ensure_lds(kern, lds);
         if (rc == FP4_OK)
             hipLaunchKernelGGL(kern, dim3((unsigned)((M + 3) / 4)), dim3(256), lds, s, reinterpret_cast<const float *>(x),
-                               packed, absmax, reinterpret_cast<const float *>(bias), reinterpret_cast<float *>(out), (int)M,
-                               (int)K, bs_shift);
+                               packed, absmax, reinterpret_cast<const float *>(bias), reinterpret_cast<const float *>(residual),
+                               reinterpret_cast<float *>(out), (int)M, (int)K, bs_shift);
     } else {
         switch (dtype) {
             case FP4_DTYPE_F16:
-                rc = run_generic<FP4_DTYPE_F16>(x, packed, absmax, bias, out, M, K, blocksize, out_f32, s);
+                rc = run_generic<FP4_DTYPE_F16>(x, packed, absmax, bias, residual, out, M, K, blocksize, mode, s);
                 break;
             case FP4_DTYPE_BF16:
-                rc = run_generic<FP4_DTYPE_BF16>(x, packed, absmax, bias, out, M, K, blocksize, out_f32, s);
+                rc = run_generic<FP4_DTYPE_BF16>(x, packed, absmax, bias, residual, out, M, K, blocksize, mode, s);
                 break;
             default:
-                rc = run_generic<FP4_DTYPE_F32>(x, packed, absmax, bias, out, M, K, blocksize, out_f32, s);
+                rc = run_generic<FP4_DTYPE_F32>(x, packed, absmax, bias, residual, out, M, K, blocksize, mode, s);
                 break;
         }
+    }
+    if (rc == -2) {
+        set_error("fp4_hip_gemv_fused: the gate|up epilogue is not available for M=%lld K=%lld blocksize=%d dtype=%d "
+                  "(needs a 16-bit dtype, K %% 32 == 0, K <= 16384 or 28672, a power-of-two blocksize >= 32 that divides K); run the plain GEMV and "
+                  "apply the activation separately", (long long)M, (long long)K, blocksize, dtype);
+        return FP4_ERR_UNSUPPORTED;
     }
     if (rc != FP4_OK) return rc;
     return check_launch("fp4_hip_gemv");
@@ -886,10 +930,20 @@ int gemv_entry(const void *x, const uint8_t *packed, const float *absmax, const 
 
 extern "C" int fp4_hip_gemv(const void *x, const uint8_t *packed, const float *absmax, const void *bias, void *out,
                             int64_t M, int64_t K, int blocksize, int dtype, void *stream) {
-    return fp4::gemv_entry(x, packed, absmax, bias, out, M, K, blocksize, dtype, 0, stream);
+    return fp4::gemv_entry(x, packed, absmax, bias, nullptr, out, M, K, blocksize, dtype, 0, stream);
+}
+
+extern "C" int fp4_hip_gemv_fused(const void *x, const uint8_t *packed, const float *absmax, const void *bias, const void *residual,
+                                  void *out, int64_t M, int64_t K, int blocksize, int dtype, int epilogue, void *stream) {
+    if (epilogue != FP4_EPILOGUE_NONE && epilogue != FP4_EPILOGUE_SILU_MUL_PAIRS) {
+        fp4::set_error("fp4_hip_gemv_fused: unknown epilogue %d", epilogue);
+        return FP4_ERR_INVALID_ARGUMENT;
+    }
+    return fp4::gemv_entry(x, packed, absmax, bias, residual, out, M, K, blocksize, dtype,
+                           epilogue == FP4_EPILOGUE_SILU_MUL_PAIRS ? fp4::kModeSiluMulPairs : 0, stream);
 }
 
 extern "C" int fp4_hip_gemv_partial(const void *x, const uint8_t *packed, const float *absmax, float *out_f32, int64_t M,
                                     int64_t K, int blocksize, int x_dtype, void *stream) {
-    return fp4::gemv_entry(x, packed, absmax, nullptr, out_f32, M, K, blocksize, x_dtype, 1, stream);
+    return fp4::gemv_entry(x, packed, absmax, nullptr, nullptr, out_f32, M, K, blocksize, x_dtype, fp4::kModeOutF32, stream);
 }

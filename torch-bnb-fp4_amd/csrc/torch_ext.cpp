@@ -12,7 +12,7 @@
 //   * launch / dtype failures raise instead of printf (csrc/dequant_fp4_optimized.cu:48-53,201-203);
 //   * qlinear_codebook* dequantise all M*N elements (the reference passes the BYTE count,
 //     csrc/torch_fp4.cpp:90,101, leaving half of the weight uninitialised).
-// Extra exports (not in the reference): gemv_fp4_bias, gemm_small_fp4, gemv_fp4_partial, quantize_fp4, set_kernel_variant, code_table.
+// Extra exports (not in the reference): gemv_fp4_bias, gemv_fp4_fused, gemm_small_fp4, gemv_fp4_partial, quantize_fp4, set_kernel_variant, code_table.
 #include <c10/core/DeviceGuard.h>
 #include <c10/hip/HIPStream.h>
 #include <torch/extension.h>
@@ -181,6 +181,49 @@ torch::Tensor gemv_fp4_bias(torch::Tensor A, torch::Tensor B, torch::Tensor absm
     return gemv_impl(A, B, absmax, datatype, blocksize, dtype, Bshape, bias);
 }
 
+// GEMV with a fused epilogue (fp4_hip_gemv_fused): bias, residual add, and - for a weight whose rows interleave a gate and an
+// up projection - silu(gate) * up.  A is [1, K] / [1, 1, K]; the result is [.., m] or, for the gated epilogue, [.., m / 2].
+torch::Tensor gemv_fp4_fused(torch::Tensor A, torch::Tensor B, torch::Tensor absmax, int blocksize, std::vector<uint32_t> Bshape,
+                             c10::optional<torch::Tensor> bias, c10::optional<torch::Tensor> residual, int epilogue) {
+    check_gpu_contiguous(A, "A");
+    check_gpu_contiguous(B, "B");
+    check_gpu_contiguous(absmax, "absmax");
+    TORCH_CHECK(Bshape.size() == 2, "Bshape must be the [out_features, in_features] of the quantised weight");
+    const int64_t m = Bshape[0], k = Bshape[1];
+    TORCH_CHECK(epilogue == FP4_EPILOGUE_NONE || epilogue == FP4_EPILOGUE_SILU_MUL_PAIRS, "gemv_fp4_fused: unknown epilogue ", epilogue);
+    const int64_t m_out = epilogue == FP4_EPILOGUE_SILU_MUL_PAIRS ? m / 2 : m;
+    const int dt = to_fp4_dtype(A.scalar_type(), "gemv_fp4_fused");
+    TORCH_CHECK(absmax.scalar_type() == torch::kFloat32, "Only fp32 absmax is supported");
+    TORCH_CHECK(B.dtype() == torch::kUInt8, "B must be uint8");
+    TORCH_CHECK(A.dim() >= 1 && A.numel() == k && A.size(-1) == k, "gemv_fp4_fused is batch-1 only: activation has ", A.numel(),
+                " elements, in_features is ", k);
+    TORCH_CHECK(B.numel() * 2 >= m * k, "B holds ", B.numel(), " bytes, ", m * k / 2, " needed");
+    TORCH_CHECK(absmax.numel() * int64_t(blocksize) >= m * k, "absmax too small for a ", m, "x", k, " weight");
+    TORCH_CHECK(B.device() == A.device() && absmax.device() == A.device(), "all tensors must be on one device");
+    auto shape = A.sizes().vec();
+    shape.back() = m_out;
+    torch::Tensor out = torch::empty(shape, A.options());
+    const void *bias_ptr = nullptr, *res_ptr = nullptr;
+    torch::Tensor bias_c, res_c;
+    if (bias.has_value()) {
+        TORCH_CHECK(bias->is_cuda() && bias->numel() == m && bias->scalar_type() == A.scalar_type(), "bias must be a [", m,
+                    "] tensor of the activation dtype");
+        bias_c = bias->contiguous();
+        bias_ptr = bias_c.data_ptr();
+    }
+    if (residual.has_value()) {
+        TORCH_CHECK(residual->is_cuda() && residual->numel() == m_out && residual->scalar_type() == A.scalar_type() &&
+                        residual->device() == A.device(),
+                    "residual must hold ", m_out, " elements of the activation dtype on the activation's device");
+        res_c = residual->contiguous();
+        res_ptr = res_c.data_ptr();
+    }
+    c10::DeviceGuard guard(A.device());
+    check_status(fp4_hip_gemv_fused(A.data_ptr(), B.data_ptr<uint8_t>(), absmax.data_ptr<float>(), bias_ptr, res_ptr, out.data_ptr(), m, k,
+                                    blocksize, dt, epilogue, current_stream(A)));
+    return out;
+}
+
 // fused small-batch product: A [..., K] with 1..16 rows in total -> [..., m]; raises if the shape is not covered
 torch::Tensor gemm_small_fp4(torch::Tensor A, torch::Tensor B, torch::Tensor absmax, int blocksize, std::vector<uint32_t> Bshape,
                              c10::optional<torch::Tensor> bias) {
@@ -273,10 +316,15 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("qlinear_codebook_bias", &qlinear_codebook_bias, "codebook dequant + linear + bias");
     // extras
     m.def("gemv_fp4_bias", &gemv_fp4_bias, "gemv_fp4 with the bias add fused into the epilogue");
+    m.def("gemv_fp4_fused", &gemv_fp4_fused,
+          "GEMV with a fused epilogue: (A, B, absmax, blocksize, Bshape, bias|None, residual|None, epilogue) ; epilogue 0 = bias/residual, "
+          "1 = silu(gate) * up over interleaved rows");
     m.def("gemm_small_fp4", &gemm_small_fp4, "fused FP4 product for 1..16 activation rows: (A, B, absmax, blocksize, Bshape, bias|None)");
     m.def("gemv_fp4_partial", &gemv_fp4_partial, "f32 partial sums of a K-split shard: (A, B, absmax, blocksize, Bshape)");
     m.def("quantize_fp4", &quantize_fp4, "blockwise FP4 quantiser: (W, blocksize) -> (packed, absmax)");
     m.def("code_table", &code_table, "16-entry code table as a CPU float tensor");
     m.def("set_kernel_variant", &set_kernel_variant, "benchmark hook: select a kernel geometry");
+    m.attr("EPILOGUE_NONE") = (int)FP4_EPILOGUE_NONE;
+    m.attr("EPILOGUE_SILU_MUL_PAIRS") = (int)FP4_EPILOGUE_SILU_MUL_PAIRS;
     m.attr("abi_version") = fp4_hip_abi_version();
 }
