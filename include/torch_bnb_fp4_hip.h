@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FP4_HIP_ABI_VERSION 3
+#define FP4_HIP_ABI_VERSION 4
 #define FP4_HIP_API __attribute__((visibility("default")))
 
 /* Element types, numbered like the reference's ScalarTypeEnum (csrc/torch_fp4.cpp:22-26). */
@@ -133,6 +133,35 @@ FP4_HIP_API int fp4_hip_gemm_small(const void *x, const uint8_t *packed, const f
  */
 FP4_HIP_API int fp4_hip_gemv_partial(const void *x, const uint8_t *packed, const float *absmax, float *out_f32, int64_t M,
                                      int64_t K, int blocksize, int x_dtype, void *stream);
+
+/*
+ * One-shot all-reduce for the K-split partials (the reference has no multi-GPU path).
+ *
+ * Setup (host side, synchronous, once): every rank allocates one slot buffer of fp4_hip_comm_bytes(world, capacity) bytes
+ * with fp4_hip_comm_alloc (zero-filled device memory, uncached / fine-grained where the runtime offers it; `kind_out`
+ * reports 0 uncached, 1 fine-grained, 2 plain), sends the 64-byte IPC handle to its peers by whatever channel the host
+ * program has (torch.distributed all_gather in torch_bnb_fp4/comm.py) and maps theirs with fp4_hip_comm_open.
+ *
+ * fp4_hip_allreduce_oneshot(partial, peer_buffers, rank, world, M, capacity, bias, residual, out, dtype, timeout_us, stream):
+ *   out[e] = T( T( T( sum_{p < world} partial_p[e] ) + bias[e] ) + residual[e] ),   e < M <= capacity,
+ * the sum taken in f32 in rank order (identical bits on every rank).  `peer_buffers` is a HOST array of `world` device
+ * pointers, entry `rank` being this rank's own buffer.  Each rank writes its partial as 8-byte {epoch, value} granules
+ * straight into its slot of every peer's buffer (one hop over all xGMI links at once) and sweeps its own buffer until
+ * all `world` slots carry the call's epoch; the epoch lives in device memory and slots are double-buffered, so the call
+ * needs no host involvement and is HIP-graph capturable.  All ranks must issue their calls on a communicator in the
+ * same order, one stream per rank.  Polling is bounded: after `timeout_us` (<= 0: 2 s) without a peer's data a lane
+ * records {epoch, peer} in the buffer's status word and writes NaN; fp4_hip_comm_status copies {epoch, busy, status,
+ * lanes timed out} to the host (synchronous) so the caller can raise.
+ */
+FP4_HIP_API int64_t fp4_hip_comm_bytes(int world, int64_t capacity);
+FP4_HIP_API int fp4_hip_comm_alloc(int64_t bytes, void **ptr, uint8_t handle_out[64], int *kind_out);
+FP4_HIP_API int fp4_hip_comm_open(const uint8_t handle[64], void **ptr);
+FP4_HIP_API int fp4_hip_comm_close(void *ptr);
+FP4_HIP_API int fp4_hip_comm_free(void *ptr);
+FP4_HIP_API int fp4_hip_comm_status(const void *own_buffer, uint32_t out4[4]);
+FP4_HIP_API int fp4_hip_allreduce_oneshot(const float *partial, void *const *peer_buffers, int rank, int world, int64_t M,
+                              int64_t capacity, const void *bias, const void *residual, void *out, int out_dtype,
+                              int64_t timeout_us, void *stream);
 
 /*
  * Blockwise FP4 quantiser (the producer side; bitsandbytes' quantize_fp4 as called at

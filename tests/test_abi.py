@@ -26,7 +26,8 @@ def test_header_symbols_are_exported():
 
 def test_abi_version_and_tables():
     l = hipabi.lib()
-    assert l.fp4_hip_abi_version() == 2
+    header = open(hipabi.HEADER).read()
+    assert l.fp4_hip_abi_version() == int(header.split('#define FP4_HIP_ABI_VERSION')[1].split()[0]) == 4
     for which, tab in ((hipabi.TABLE_CODEBOOK, o.CODEBOOK_TABLE), (hipabi.TABLE_TREE, o.TREE_TABLE)):
         out = np.zeros(16, np.float32)
         assert l.fp4_hip_code_table(which, out.ctypes.data_as(ctypes.c_void_p)) == hipabi.OK
@@ -49,6 +50,21 @@ def test_argument_validation_without_gpu():
     assert l.fp4_hip_gemv(one, one, one, None, one, 4, 64, 64, 9, None) == hipabi.ERR_UNSUPPORTED
     assert l.fp4_hip_gemv(None, None, None, None, None, 0, 64, 64, hipabi.BF16, None) == hipabi.OK  # M == 0
     assert l.fp4_hip_quantize_blockwise(one, hipabi.F16, one, one, 64, 48, None) == hipabi.ERR_UNSUPPORTED
+    # fused epilogues and the one-shot all-reduce: argument errors are reported before anything touches a GPU
+    l.fp4_hip_gemv_fused.argtypes = [ctypes.c_void_p] * 6 + [ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    assert l.fp4_hip_gemv_fused(one, one, one, None, None, one, 4, 64, 64, hipabi.BF16, 9, None) == hipabi.ERR_INVALID  # unknown epilogue
+    assert l.fp4_hip_gemv_fused(one, one, one, None, None, one, 5, 64, 64, hipabi.BF16, 1, None) == hipabi.ERR_INVALID  # odd rows, gate|up
+    assert "even row count" in hipabi.last_error()
+    l.fp4_hip_comm_bytes.restype = ctypes.c_int64
+    l.fp4_hip_comm_bytes.argtypes = [ctypes.c_int, ctypes.c_int64]
+    assert l.fp4_hip_comm_bytes(8, 16384) == 256 + 2 * 8 * 16384 * 8 and l.fp4_hip_comm_bytes(17, 1) == -1 and l.fp4_hip_comm_bytes(2, 0) == -1
+    l.fp4_hip_allreduce_oneshot.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
+                                            ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_void_p]
+    bufs = (ctypes.c_void_p * 2)(16, 16)
+    assert l.fp4_hip_allreduce_oneshot(one, bufs, 2, 2, 64, 1024, None, None, one, hipabi.BF16, 0, None) == hipabi.ERR_INVALID  # rank >= world
+    assert l.fp4_hip_allreduce_oneshot(one, bufs, 0, 2, 2048, 1024, None, None, one, hipabi.BF16, 0, None) == hipabi.ERR_INVALID  # M > capacity
+    assert l.fp4_hip_allreduce_oneshot(one, bufs, 0, 2, 64, 1024, None, None, one, 9, 0, None) == hipabi.ERR_UNSUPPORTED
+    assert l.fp4_hip_allreduce_oneshot(None, None, 0, 2, 0, 1024, None, None, None, hipabi.BF16, 0, None) == hipabi.OK  # nothing to do
     assert l.fp4_hip_set_variant(b"nope", 1) == hipabi.ERR_INVALID
     assert l.fp4_hip_set_variant(b"gemv", -1) == hipabi.OK
 

@@ -12,7 +12,7 @@
 //   * launch / dtype failures raise instead of printf (csrc/dequant_fp4_optimized.cu:48-53,201-203);
 //   * qlinear_codebook* dequantise all M*N elements (the reference passes the BYTE count,
 //     csrc/torch_fp4.cpp:90,101, leaving half of the weight uninitialised).
-// Extra exports (not in the reference): gemv_fp4_bias, gemv_fp4_fused, gemm_small_fp4, gemv_fp4_partial, quantize_fp4, set_kernel_variant, code_table.
+// Extra exports (not in the reference): gemv_fp4_bias, gemv_fp4_fused, comm_* / allreduce_oneshot, gemm_small_fp4, gemv_fp4_partial, quantize_fp4, set_kernel_variant, code_table.
 #include <c10/core/DeviceGuard.h>
 #include <c10/hip/HIPStream.h>
 #include <torch/extension.h>
@@ -287,6 +287,66 @@ std::tuple<torch::Tensor, torch::Tensor> quantize_fp4(torch::Tensor W, int block
     return {packed, absmax};
 }
 
+// ---- one-shot all-reduce plumbing (fp4_hip_comm_* / fp4_hip_allreduce_oneshot) ---------------------------------------
+// Buffers are identified by their device address (an int on the Python side); torch_bnb_fp4/comm.py owns their lifetime.
+std::tuple<int64_t, py::bytes, int> comm_alloc(int world, int64_t capacity, int device) {
+    const int64_t bytes = fp4_hip_comm_bytes(world, capacity);
+    TORCH_CHECK(bytes > 0, "comm_alloc: bad world / capacity");
+    c10::DeviceGuard guard(c10::Device(c10::kCUDA, (c10::DeviceIndex)device));
+    void *p = nullptr;
+    uint8_t handle[64];
+    int kind = -1;
+    check_status(fp4_hip_comm_alloc(bytes, &p, handle, &kind));
+    return {reinterpret_cast<int64_t>(p), py::bytes(reinterpret_cast<const char *>(handle), 64), kind};
+}
+
+int64_t comm_open(const std::string &handle, int device) {
+    TORCH_CHECK(handle.size() == 64, "comm_open: an IPC handle is 64 bytes");
+    c10::DeviceGuard guard(c10::Device(c10::kCUDA, (c10::DeviceIndex)device));
+    void *p = nullptr;
+    check_status(fp4_hip_comm_open(reinterpret_cast<const uint8_t *>(handle.data()), &p));
+    return reinterpret_cast<int64_t>(p);
+}
+
+void comm_close(int64_t ptr) { check_status(fp4_hip_comm_close(reinterpret_cast<void *>(ptr))); }
+void comm_free(int64_t ptr) { check_status(fp4_hip_comm_free(reinterpret_cast<void *>(ptr))); }
+
+std::vector<uint32_t> comm_status(int64_t own_ptr) {
+    std::vector<uint32_t> out(4);
+    check_status(fp4_hip_comm_status(reinterpret_cast<const void *>(own_ptr), out.data()));
+    return out;
+}
+
+// partial: f32 [.., M] on this rank's GPU; returns T [.., M] = T(sum over ranks) (+ bias) (+ residual)
+torch::Tensor allreduce_oneshot(torch::Tensor partial, std::vector<int64_t> peers, int rank, int64_t capacity, ScalarTypeEnum dtype,
+                                c10::optional<torch::Tensor> bias, c10::optional<torch::Tensor> residual, int64_t timeout_us) {
+    check_gpu_contiguous(partial, "partial");
+    TORCH_CHECK(partial.scalar_type() == torch::kFloat32, "allreduce_oneshot: the partial sums must be float32");
+    const int world = (int)peers.size();
+    const int64_t m = partial.numel();
+    const torch::ScalarType st = to_torch(dtype);
+    torch::Tensor out = torch::empty(partial.sizes(), partial.options().dtype(st));
+    const void *bias_ptr = nullptr, *res_ptr = nullptr;
+    torch::Tensor bias_c, res_c;
+    if (bias.has_value()) {
+        TORCH_CHECK(bias->is_cuda() && bias->numel() == m && bias->scalar_type() == st, "bias must hold ", m, " elements of ", st);
+        bias_c = bias->contiguous();
+        bias_ptr = bias_c.data_ptr();
+    }
+    if (residual.has_value()) {
+        TORCH_CHECK(residual->is_cuda() && residual->numel() == m && residual->scalar_type() == st, "residual must hold ", m,
+                    " elements of ", st);
+        res_c = residual->contiguous();
+        res_ptr = res_c.data_ptr();
+    }
+    std::vector<void *> bufs(world);
+    for (int p = 0; p < world; ++p) bufs[p] = reinterpret_cast<void *>(peers[p]);
+    c10::DeviceGuard guard(partial.device());
+    check_status(fp4_hip_allreduce_oneshot(partial.data_ptr<float>(), bufs.data(), rank, world, m, capacity, bias_ptr, res_ptr,
+                                           out.data_ptr(), (int)dtype, timeout_us, current_stream(partial)));
+    return out;
+}
+
 torch::Tensor code_table(const std::string &name) {
     TORCH_CHECK(name == "codebook" || name == "tree", "code_table: name must be 'codebook' or 'tree'");
     torch::Tensor t = torch::empty({16}, torch::kFloat32);
@@ -321,6 +381,13 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
           "1 = silu(gate) * up over interleaved rows");
     m.def("gemm_small_fp4", &gemm_small_fp4, "fused FP4 product for 1..16 activation rows: (A, B, absmax, blocksize, Bshape, bias|None)");
     m.def("gemv_fp4_partial", &gemv_fp4_partial, "f32 partial sums of a K-split shard: (A, B, absmax, blocksize, Bshape)");
+    m.def("comm_alloc", &comm_alloc, "(world, capacity, device) -> (buffer address, 64-byte IPC handle, memory kind)");
+    m.def("comm_open", &comm_open, "(handle, device) -> mapped address of a peer's buffer");
+    m.def("comm_close", &comm_close, "unmap a peer's buffer");
+    m.def("comm_free", &comm_free, "free the own buffer");
+    m.def("comm_status", &comm_status, "(own buffer) -> [epoch, busy, status, lanes timed out]  (synchronous)");
+    m.def("allreduce_oneshot", &allreduce_oneshot,
+          "one-shot all-reduce of f32 partials over peer-mapped slots: (partial, peers, rank, capacity, dtype, bias|None, residual|None, timeout_us)");
     m.def("quantize_fp4", &quantize_fp4, "blockwise FP4 quantiser: (W, blocksize) -> (packed, absmax)");
     m.def("code_table", &code_table, "16-entry code table as a CPU float tensor");
     m.def("set_kernel_variant", &set_kernel_variant, "benchmark hook: select a kernel geometry");

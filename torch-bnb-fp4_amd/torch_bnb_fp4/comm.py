@@ -1,0 +1,82 @@
+"""Peer-slot communicator for the one-shot all-reduce of the K-split layers (``fp4_hip_allreduce_oneshot``).
+
+One :class:`OneShotAllReduce` per process group: every rank allocates a slot buffer on its GPU, the 64-byte IPC handles
+travel once through ``torch.distributed`` (any backend: this is setup, not the data path), every rank maps its peers'
+buffers, and from then on a reduction is ONE kernel launch on the current stream - no RCCL call, no host
+synchronisation, HIP-graph capturable.  The reference has no multi-GPU path; design: SURVEY section 8e.
+
+All ranks must call :meth:`reduce` the same number of times in the same order on one stream each.  A peer that never
+shows up does not hang the GPU: the kernel gives up after ``timeout_us``, writes NaN and records the event in the
+buffer's status word; :meth:`check` (synchronous) raises on it.
+"""
+from __future__ import annotations
+
+import os
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+from ._ext import ext
+from .dtypes import ScalarType
+
+_KINDS = {0: "uncached", 1: "fine-grained", 2: "default"}
+
+
+class OneShotAllReduce:
+    def __init__(self, group=None, capacity: int = 16384, device: Optional[torch.device] = None, timeout_us: int = 2_000_000):
+        if not dist.is_initialized():
+            raise RuntimeError("OneShotAllReduce needs an initialised torch.distributed process group")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the host driver only supports dmabuf IPC
+        self.group = group
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.capacity = int(capacity)
+        self.timeout_us = int(timeout_us)
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self._own, handle, kind = ext.comm_alloc(self.world, self.capacity, self.device.index)
+        self.memory_kind = _KINDS.get(kind, str(kind))
+        handles = [None] * self.world
+        dist.all_gather_object(handles, (self.rank, os.getpid(), bytes(handle)), group=group)
+        self._peers, self._opened = [], []
+        for r, pid, h in handles:
+            if r == self.rank:
+                self._peers.append(self._own)
+            elif pid == os.getpid():
+                raise RuntimeError("OneShotAllReduce: two ranks in one process cannot share an IPC handle")
+            else:
+                p = ext.comm_open(h, self.device.index)
+                self._peers.append(p)
+                self._opened.append(p)
+        dist.barrier(group=group)  # nobody starts reducing before every buffer is mapped everywhere
+
+    def reduce(self, partial: torch.Tensor, out_dtype: torch.dtype, bias: Optional[torch.Tensor] = None,
+               residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """``T(sum over ranks of partial) (+ bias) (+ residual)``; ``partial`` is this rank's float32 tensor."""
+        if partial.numel() > self.capacity:
+            raise ValueError(f"OneShotAllReduce: {partial.numel()} elements exceed the capacity of {self.capacity}")
+        return ext.allreduce_oneshot(partial.contiguous(), self._peers, self.rank, self.capacity,
+                                     ScalarType.from_torch_dtype(out_dtype).value, bias, residual, self.timeout_us)
+
+    def status(self):
+        """``(completed calls, busy workgroups, status word, lanes that timed out)`` - synchronises the device."""
+        torch.cuda.synchronize(self.device)
+        return tuple(ext.comm_status(self._own))
+
+    def check(self) -> None:
+        epoch, _, status, lanes = self.status()
+        if status:
+            raise RuntimeError(f"OneShotAllReduce: rank {self.rank} timed out waiting for rank {(status & 0xFF) - 1} in call "
+                               f"{status >> 8} ({lanes} lanes gave up; {epoch} calls completed): outputs of that call are NaN")
+
+    def close(self) -> None:
+        if getattr(self, "_own", None) is None:
+            return
+        torch.cuda.synchronize(self.device)
+        try:
+            dist.barrier(group=self.group)  # peers may still be reading our slots
+        except Exception:
+            pass
+        for p in self._opened:
+            ext.comm_close(p)
+        ext.comm_free(self._own)
+        self._own, self._peers, self._opened = None, [], []

@@ -9,7 +9,8 @@ The reference has no multi-GPU code at all; this module is the SURVEY section 8e
 * a **column range** is strided -> K-split ("row-parallel") shards are re-packed once at load time into their own
   contiguous ``[M, K/G/2]`` bytes + ``[M*K/G/bs]`` scales; each rank produces a full-length f32 partial
   (``gemv_fp4_partial``) and the partials are summed with one all-reduce (16 KiB at M = 4096: latency-bound),
-  then rounded to the activation dtype once.
+  then rounded to the activation dtype once.  ``allreduce="dist"`` uses ``torch.distributed`` (RCCL);
+  ``allreduce="oneshot"`` the peer-slot kernel of :mod:`torch_bnb_fp4.comm` (one launch, HIP-graph capturable).
 """
 from __future__ import annotations
 
@@ -83,6 +84,20 @@ def _all_gather_last(y: torch.Tensor, world: int, group) -> torch.Tensor:
     return torch.cat(parts, dim=-1).to(y.device)
 
 
+_COMMS = {}
+
+
+def oneshot_comm(group=None, capacity: int = 16384):
+    """The process group's shared :class:`~torch_bnb_fp4.comm.OneShotAllReduce` (created on first use: a collective call)."""
+    from .comm import OneShotAllReduce
+
+    key = (id(group) if group is not None else None, torch.cuda.current_device())
+    comm = _COMMS.get(key)
+    if comm is None or comm.capacity < capacity:
+        comm = _COMMS[key] = OneShotAllReduce(group, capacity=max(capacity, 16384))
+    return comm
+
+
 def _quant_data(packed, absmax, shape, blocksize, bias, use_codebook_dequant=True) -> QuantData:
     state = QuantState(absmax, shape, fp4_code().to(packed.device), blocksize)
     return QuantData(packed, state, state.shape, original_lin=None, bias=bias, use_codebook_dequant=use_codebook_dequant)
@@ -128,20 +143,29 @@ class RowParallelFP4Linear(nn.Module):
         self.input_is_parallel = input_is_parallel
         self.out_features, self.in_features = int(shape[0]), int(shape[1])
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
         ks = self.local_shape[1]
         xs = x if self.input_is_parallel else x[..., self.rank * ks:(self.rank + 1) * ks]
         qd = self.quant_data
-        if xs.numel() == ks:  # single token: fused GEMV, raw f32 accumulator out
+        single = xs.numel() == ks
+        if single:  # single token: fused GEMV, raw f32 accumulator out
             part = ext.gemv_fp4_partial(xs.reshape(1, ks).contiguous(), qd.A.t(), qd.absmax, self.blocksize, list(self.local_shape))
             part = part.view(*x.shape[:-1], self.out_features)
-        else:  # batch / sequence: dequant + GEMM, partial kept in f32 for the sum
+        else:  # batch / sequence: dequantise to f32 and multiply in f32, so the partial carries no rounding to T
             if not qd.compute_dtype_set:
                 qd.set_compute_type(xs)
-            part = torch.nn.functional.linear(xs, qd.dequantize()).float()
+            w32 = ext.dequantize_fp4_codebook(qd.A, qd.absmax, qd.code, qd.M, qd.N, qd.blocksize, qd.numel, ScalarType.float32.value)
+            part = torch.nn.functional.linear(xs.float(), w32)
+        if self.world > 1 and self.allreduce == "oneshot" and part.is_cuda:
+            # one launch: publish into every peer's slots, gather, sum in rank order, round once, bias / residual on top
+            comm = oneshot_comm(self.group, part.numel())
+            bias = None if self.bias is None else self.bias.to(x.dtype)
+            if bias is not None and part.numel() != self.out_features:
+                bias = bias.expand(part.shape).contiguous()
+            return comm.reduce(part, x.dtype, bias, residual)
         if self.world > 1:
             part = _all_reduce_sum(part, self.group)
         y = part.to(x.dtype)
         if self.bias is not None:
             y = y + self.bias.to(x.dtype)
-        return y
+        return y if residual is None else y + residual
