@@ -278,6 +278,20 @@ def test_state_dict_and_device_move():
     assert fp4.qweight.device.type == "cpu" and fp4.quant_data.A.device.type == "cpu"
     fp4.to(dev())
     assert torch.equal(fp4(x), y)
+    # the registered buffers ARE what the kernels use: the bias buffer follows the cast to the compute dtype ...
+    assert fp4.state_dict()["bias"].dtype == torch.bfloat16 and fp4.bias.data_ptr() == fp4.quant_data.bias.data_ptr()
+    assert fp4.qweight.data_ptr() == fp4.quant_data.A.data_ptr() and fp4.absmax.data_ptr() == fp4.quant_data.absmax.data_ptr()
+    # ... the wrapped layer kept in .lin shares the moved tensors instead of pinning old copies ...
+    assert fp4.lin[0].weight.data.data_ptr() == fp4.qweight.data_ptr() and fp4.lin[0].weight.quant_state.absmax.data_ptr() == fp4.absmax.data_ptr()
+    # ... and a load_state_dict AFTER the first forward reaches the kernels (new bias, new scales)
+    sd2 = {k: v.clone() for k, v in fp4.state_dict().items()}
+    sd2["bias"] = (sd2["bias"].float() + 1.0).to(torch.bfloat16)
+    sd2["absmax"] = sd2["absmax"] * 2.0
+    fp4.load_state_dict(sd2)
+    y2 = fp4(x)
+    want = (2.0 * (y.float() - sd["bias"].to(dev()).to(torch.bfloat16).float())) + sd2["bias"].float()
+    assert (y2.float() - want).abs().max().item() <= 0.02 * want.abs().max().item() + 0.02
+    assert (y2.float() - y.float()).abs().max().item() > 0.5
     assert "TorchFP4Linear(in_features=256, out_features=128, bias=True" in repr(fp4)
 
 

@@ -228,3 +228,34 @@ def test_product_package_never_imports_the_oracle():
                 text = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, re.M), f
                 assert "fp4_oracle" not in text.replace("oracle/fp4_oracle.py", ""), f
+
+
+def test_bnb_state_keys_match_the_installed_transformers_loader():
+    """the on-disk layout is pinned against something other than ourselves - the key patterns the
+    installed transformers' pre-quantised bitsandbytes 4-bit loader collects per Linear (quantizer_bnb_4bit.get_weight_conversions;
+    importable without bitsandbytes).  What stays 'parity unpinned': the JSON payload of weight.quant_state.bitsandbytes__fp4 -
+    a genuine bitsandbytes file carries quant_type, blocksize, dtype, shape (plus nested_blocksize / nested_dtype / nested_offset
+    when double quantisation is on, which neither the reference, README.md:223-224, nor this package supports); ours writes the
+    same four fields, restated from bitsandbytes' QuantState.as_dict, with no bitsandbytes-written file available to compare."""
+    import json
+    import types
+
+    from transformers import BitsAndBytesConfig
+    from transformers.quantizers.quantizer_bnb_4bit import Bnb4BitHfQuantizer
+
+    conv = Bnb4BitHfQuantizer(BitsAndBytesConfig(load_in_4bit=True, bnb_4bit_quant_type="fp4"), pre_quantized=True).get_weight_conversions()
+    assert len(conv) == 1 and conv[0].target_patterns == ["weight"]
+    patterns = set(conv[0].source_patterns)
+    qd, _, lin = make_quant_data(64, 128)
+    qd.bias = lin.bias.detach()
+    layer = types.SimpleNamespace(quant_data=qd, bias=qd.bias)
+    prefix = "model.layers.0.self_attn.q_proj."
+    state = pkg.fp4_linear_to_bnb_state(layer, prefix)
+    ours = {k[len(prefix):] for k in state} - {"bias"}
+    assert ours <= patterns, ours - patterns                      # every key we write is one the loader collects
+    required = {p for p in patterns if "nested" not in p and "nf4" not in p}
+    assert ours == required, (ours, required)                     # and we write all of the non-nested FP4 ones
+    meta = json.loads(bytes(state[prefix + "weight.quant_state.bitsandbytes__fp4"].tolist()).decode())
+    assert meta == {"quant_type": "fp4", "blocksize": 64, "dtype": "float16", "shape": [64, 128]}
+    assert state[prefix + "weight"].dtype == torch.uint8 and tuple(state[prefix + "weight"].shape) == (64 * 128 // 2, 1)
+    assert state[prefix + "weight.absmax"].dtype == torch.float32 and state[prefix + "weight.quant_map"].numel() == 16

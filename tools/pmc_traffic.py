@@ -13,12 +13,20 @@ import sys
 
 
 def per_kernel(path, counter):
-    acc = collections.defaultdict(list)
+    """Mean counter value per (kernel, grid): one kernel name serves several problem sizes in bench.py (the 4096x4096 launches
+    of the timed region and the one-launch stack of R weights), so launches are grouped by grid size as well; the most
+    frequent grid of a kernel keeps the bare name (that is the timed region's), the others get a `grid=N` suffix."""
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] == counter and "fp4::" in r["Kernel_Name"]:
-            name = r["Kernel_Name"].split("(unsigned")[0].replace("void fp4::(anonymous namespace)::", "").strip()
-            acc[name].append(float(r["Counter_Value"]))
-    return {k: (statistics.mean(v), len(v)) for k, v in acc.items()}
+            name = r["Kernel_Name"].split("(unsigned")[0].split("(void")[0].replace("void fp4::(anonymous namespace)::", "").strip()
+            acc[name][int(r["Grid_Size"])].append(float(r["Counter_Value"]))
+    out = {}
+    for name, grids in acc.items():
+        main = max(grids, key=lambda g: len(grids[g]))
+        for g, v in grids.items():
+            out[name if g == main else f"{name} grid={g}"] = (statistics.mean(v), len(v))
+    return out
 
 
 fetch = per_kernel(sys.argv[1], "FETCH_SIZE")

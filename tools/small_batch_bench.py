@@ -13,7 +13,9 @@ import hipabi  # noqa: E402
 
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
-R, dev, n = 64, torch.device("cuda", 0), M * K
+QUICK = "--quick" in sys.argv  # default dispatch only, next to the batch-1 GEMV on the same weights (the "same bytes" yardstick)
+dev, n = torch.device("cuda", 0), M * K
+R = max(8, min(64, int(1.2e9 / (n * 0.5625))))
 gen = torch.Generator(device=dev).manual_seed(0)
 packed = [torch.randint(0, 256, (n // 2,), dtype=torch.uint8, device=dev, generator=gen) for _ in range(R)]
 absmax = [torch.rand(n // 64, device=dev, generator=gen) * 0.1 + 0.01 for _ in range(R)]
@@ -38,6 +40,17 @@ def timeit(replay, launches, reps=7):
         ts.append(a.elapsed_time(b) * 1e3 / launches)
     return statistics.median(ts)
 
+
+if QUICK:
+    x1 = torch.randn(K, device=dev).to(torch.bfloat16)
+    t_gemv = timeit(capture(lambda: [hipabi.gemv(x1, packed[i], absmax[i], M, K, 64) for i in range(R)]), R)
+    line = [f"{M}x{K} bf16: gemv {t_gemv:6.2f} us |"]
+    for B in (2, 4, 8, 16):
+        x = torch.randn(B, K, device=dev).to(torch.bfloat16)
+        t = timeit(capture(lambda: [hipabi.gemm_small(x, packed[i], absmax[i], M, K, 64) for i in range(R)]), R)
+        line.append(f"batch {B:2d}: {t:6.2f} us ({t / t_gemv:4.2f}x)")
+    print("  ".join(line), flush=True)
+    sys.exit(0)
 
 for B in (1, 2, 3, 4, 8, 12, 16):
     x = torch.randn(B, K, device=dev).to(torch.bfloat16)

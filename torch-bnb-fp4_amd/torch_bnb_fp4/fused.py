@@ -96,6 +96,14 @@ class FusedFP4Linear(nn.Module):
             raise ValueError("gate_up() needs two projections of the same shape and blocksize")
         return cls.gate_up_from_packed((g.A, g.absmax), (u.A, u.absmax), (g.M, g.N), g.blocksize, g.bias, u.bias)
 
+    def _apply(self, fn, recurse=True):
+        super()._apply(fn, recurse)
+        qd = self.quant_data
+        if self.qweight.device != qd.A.device:  # device move: the dispatcher follows the buffers
+            bias = None if qd.bias is None else qd.bias.to(self.qweight.device)
+            qd.rebind(self.qweight, self.absmax, qd.code.to(self.qweight.device), bias)
+        return self
+
     # -- forward -----------------------------------------------------------------------------------------------------
     def _unfused(self, x: torch.Tensor, residual: Optional[torch.Tensor]) -> torch.Tensor:
         y = self.quant_data.forward(x)
@@ -113,7 +121,7 @@ class FusedFP4Linear(nn.Module):
             if not x.is_contiguous():
                 x = x.contiguous()
             try:
-                return ext.gemv_fp4_fused(x, qd.A.t(), qd.absmax, qd.blocksize, qd._shape_list, qd.bias, residual, self.epilogue)
+                return ext.gemv_fp4_fused(x, qd._B_t, qd.absmax, qd.blocksize, qd._shape_list, qd.bias, residual, self.epilogue)
             except RuntimeError as exc:
                 if "not available" not in str(exc):
                     raise

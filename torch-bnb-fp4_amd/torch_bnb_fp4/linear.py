@@ -35,19 +35,42 @@ class TorchFP4Linear(nn.Module):
         self.register_buffer("code", self.quant_data.code, persistent=True)
         self.register_buffer("bias", None if self.quant_data.bias is None else self.quant_data.bias.detach(), persistent=True)
 
+    def _sync_from_buffers(self) -> None:
+        """The registered buffers are the single source of truth: the dispatcher (and the wrapped layer kept in ``self.lin``)
+        are re-pointed at them, so nothing keeps a stale or old-device copy alive."""
+        self.quant_data.rebind(self.qweight, self.absmax, self.code, self.bias)
+        self._buffers["absmax"], self._buffers["code"] = self.quant_data.absmax, self.quant_data.code
+        if self.quant_data.bias is not None:
+            self._buffers["bias"] = self.quant_data.bias
+        lin = self.lin[0]
+        w = getattr(lin, "weight", None)
+        if w is not None and getattr(w, "quant_state", None) is not None:
+            w.data = self.qweight
+            w.quant_state.absmax, w.quant_state.code = self.absmax, self.code
+        if getattr(lin, "bias", None) is not None and self.bias is not None and lin.bias.device != self.bias.device:
+            lin.bias.data = lin.bias.data.to(self.bias.device)
+
     def _apply(self, fn, recurse=True):
         # only device moves are honoured: the packed bytes and f32 scales never change dtype
         probe = fn(torch.empty(0, dtype=torch.float16, device=self.qweight.device))
         if probe.device != self.qweight.device:
             mv = lambda t: None if t is None else t.to(probe.device)
-            self.qweight, self.absmax, self.code, self.bias = mv(self.qweight), mv(self.absmax), mv(self.code), mv(self.bias)
-            qd = self.quant_data
-            qd.A, qd.absmax, qd.code = self.qweight, self.absmax, self.code
-            qd.bias = None if qd.bias is None else qd.bias.to(probe.device)
+            for name in ("qweight", "absmax", "code", "bias"):
+                self._buffers[name] = mv(self._buffers[name])
+            self._sync_from_buffers()
         return self
 
+    def _load_from_state_dict(self, *args, **kwargs):
+        super()._load_from_state_dict(*args, **kwargs)
+        self._sync_from_buffers()  # load_state_dict copies into the buffers in place; the bias may need its cast redone
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        return self.quant_data.forward(x)
+        qd = self.quant_data
+        if not qd.compute_dtype_set and x.numel():
+            qd.set_compute_type(x)  # casts the bias to the activation dtype (reference :417-421) ...
+            if qd.bias is not None:
+                self._buffers["bias"] = qd.bias  # ... and the registered buffer follows, so state_dict() shows what the kernels use
+        return qd.forward(x)
 
     def __repr__(self) -> str:
         dt = getattr(getattr(self, "quant_data", None), "o_type", None)

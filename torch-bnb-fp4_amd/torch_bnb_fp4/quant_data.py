@@ -13,8 +13,10 @@ numel == last dim, other ranks        ``qlinear``                        (:614-6
 everything else (batch or seq > 1)    ``qlinear`` = dequant + F.linear   (:616-617)
 ====================================  =========================================
 
-Opt-in extensions (off by default so the table above holds): ``fuse_bias`` folds the post-GEMV bias add into the
-kernel epilogue (bit-identical); ``small_batch_fused`` sends 2..32 activation rows to the fused small-batch kernels.
+Two extensions.  ``fuse_bias`` (ON by default) folds the post-GEMV ``out += bias`` into the kernel epilogue: the table above
+still holds and the result is bit-identical (``T(T(sum) + bias)``), there is just one launch fewer; ``fuse_bias=False`` runs the
+reference's two-step sequence literally.  ``small_batch_fused`` (OFF by default, because it changes the table's last row) sends
+2..32 activation rows to the fused small-batch kernels instead of dequant + GEMM.
 """
 from __future__ import annotations
 
@@ -60,6 +62,18 @@ class QuantData:
         else:
             self.qlinear = self._dequant_linear
         self.dequantize = self._dequantize_codebook if use_codebook_dequant else self._dequantize_normal
+
+    def rebind(self, A: torch.Tensor, absmax: torch.Tensor, code: torch.Tensor, bias: Optional[torch.Tensor]) -> None:
+        """Point the dispatcher at new storage for the packed weight / scales / code / bias (after a device move or a
+        ``load_state_dict`` of the owning module); the bias is cast to the compute dtype if that is already fixed."""
+        self.A, self.absmax, self.code = A, absmax.float(), code.float()
+        self._B_t = A.t()
+        if bias is not None and self.compute_dtype_set:
+            bias = bias.to(dtype=self.o_type)
+        self.bias = bias
+        qs = self.quant_state
+        if hasattr(qs, "absmax"):
+            qs.absmax, qs.code = self.absmax, self.code
 
     # -- compute dtype ---------------------------------------------------------------------------
     def set_compute_type(self, x: torch.Tensor) -> None:
