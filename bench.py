@@ -176,7 +176,29 @@ def c5_leg(dist, backend, rank, world, dev, barrier, tokens=16):
     # the one-shot peer-slot all-reduce (no RCCL call inside the step) is always captured
     modes = [("dist", os.environ.get("FP4_BENCH_C5_GRAPH", "0") == "1" and backend == "nccl")]
     if os.environ.get("FP4_BENCH_C5_ONESHOT", "1") == "1":
-        modes.append(("oneshot", True))
+        # The peer-slot path has only ever run with ranks sharing one GPU: before it is trusted across xGMI, ONE reduction
+        # with a 50 ms give-up is checked against torch.distributed on every rank; any doubt and the leg is skipped.
+        try:
+            from torch_bnb_fp4 import parallel as par
+
+            comm = par.oneshot_comm(None)
+            comm.timeout_us = 50_000
+            probe = torch.arange(4096, device=dev, dtype=torch.float32) * (rank + 1) * 0.25
+            got = comm.reduce(probe, torch.float32)
+            want = probe.clone()
+            if backend == "nccl":
+                dist.all_reduce(want)
+            else:
+                h = want.cpu()
+                dist.all_reduce(h)
+                want = h.to(dev)
+            ok = torch.tensor([int(comm.status()[2] == 0 and torch.equal(got, want))], device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            out["oneshot_selfcheck"] = {"ok": bool(ok.item()), "memory_kind": comm.memory_kind}
+            if ok.item():
+                modes.append(("oneshot", True))
+        except Exception as exc:
+            out["oneshot_selfcheck"] = {"ok": False, "error": repr(exc)[:300]}
     for ar, graph in modes:
         try:
             token, h0, meta = db.build_token_fn(cfg, dev, torch.bfloat16, world, rank, allreduce=ar, lm_head=False)
@@ -186,6 +208,11 @@ def c5_leg(dist, backend, rank, world, dev, barrier, tokens=16):
                        "graph_ms_per_token": None if t["graph_s"] is None else round(t["graph_s"] * 1e3, 3),
                        "graph_error": t["graph_error"],
                        "fp4_gbps_per_gpu": round(meta["fp4_bytes_per_token_per_gpu"] / best / 1e9, 1)}
+            if ar == "oneshot":
+                from torch_bnb_fp4 import parallel as par
+
+                st = par.oneshot_comm(None).status()
+                out[ar]["timeouts"] = int(st[3])  # lanes that gave up waiting for a peer (must be 0 for the figure to count)
             out["allreduces_per_token"] = meta["allreduces_per_token"]
             out["fp4_bytes_per_token_per_gpu"] = meta["fp4_bytes_per_token_per_gpu"]
             del token, h0

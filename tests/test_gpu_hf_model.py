@@ -61,3 +61,16 @@ def test_tiny_llama_prefill_and_cached_decode(dtype):
         # greedy generation runs end to end through generate()
         gen = fp4.generate(ids, max_new_tokens=5, do_sample=False)
         assert gen.shape == (1, 11)
+        # gated-MLP fusion (gate|up in one launch with silu(g) * u in its epilogue): same model, same numbers - the fused path
+        # rounds where the separate ops round, so cached decode agrees with the unfused FP4 model to rounding noise
+        fused = P.recursively_replace_with_fp4_linear(copy.deepcopy(model), as_dtype=dtype, device=dev())  # same bytes as fp4
+        assert P.fuse_gated_mlps(fused) == cfg.num_hidden_layers
+        assert all(isinstance(l.mlp, P.FusedGatedMLP) for l in fused.model.layers)
+        o_a = fp4(ids, use_cache=True)
+        o_b = fused(ids, use_cache=True)  # prefill: unfused fallback inside the fused module
+        assert (o_a.logits.float() - o_b.logits.float()).abs().max().item() <= 0.02 * (1 + o_a.logits.float().abs().max().item())
+        nxt = o_a.logits[:, -1].argmax(-1, keepdim=True)
+        d_a = fp4(nxt, past_key_values=o_a.past_key_values, use_cache=True).logits.float()
+        d_b = fused(nxt, past_key_values=o_b.past_key_values, use_cache=True).logits.float()  # decode: fused epilogue
+        assert (d_a - d_b).abs().max().item() <= 0.02 * (1 + d_a.abs().max().item())
+        assert fused.generate(ids, max_new_tokens=5, do_sample=False).shape == (1, 11)

@@ -22,12 +22,16 @@ from .functional import (
     gemm_4bit_inference_qtype,
     quantize_fp4,
 )
+from .comm import OneShotAllReduce
+from .fused import FusedFP4Linear
 from .linear import TorchFP4Linear
 from .nn import Linear4bit, LinearFP4, Params4bit, QuantState
 from .quant_data import QuantData
 from .serialization import fp4_linear_from_bnb_state, fp4_linear_to_bnb_state, load_fp4_layers, save_fp4_model
 from .surgery import (
+    FusedGatedMLP,
     check_if_name_contained_in_list,
+    fuse_gated_mlps,
     recursively_replace_with_fp4_linear,
     set_small_batch_fused,
     swap_linear_with_bnb_linear,
@@ -58,5 +62,9 @@ __all__ = [
     "save_fp4_model",
     "load_fp4_layers",
     "set_small_batch_fused",
+    "fuse_gated_mlps",
+    "FusedGatedMLP",
+    "FusedFP4Linear",
+    "OneShotAllReduce",
 ]
 __version__ = "0.1.0"

@@ -142,3 +142,37 @@ def set_small_batch_fused(module: nn.Module, enabled: bool = True) -> int:
             n += 1
     return n
 
+
+
+class FusedGatedMLP(nn.Module):
+    """``down(silu(gate(x)) * up(x))`` with the gate and up projections as ONE launch whose epilogue applies the activation
+    and the product (:mod:`torch_bnb_fp4.fused`); what :func:`fuse_gated_mlps` puts in place of a Llama / Mistral style MLP."""
+
+    def __init__(self, gate: TorchFP4Linear, up: TorchFP4Linear, down: nn.Module):
+        super().__init__()
+        from .fused import FusedFP4Linear
+
+        self.gate_up = FusedFP4Linear.gate_up(gate, up)
+        self.down_proj = down
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return self.down_proj(self.gate_up(x))
+
+
+def fuse_gated_mlps(module: nn.Module, gate: str = "gate_proj", up: str = "up_proj", down: str = "down_proj", act: str = "act_fn") -> int:
+    """After :func:`recursively_replace_with_fp4_linear`: replace every sub-module that looks like a SiLU-gated MLP (children
+    ``gate`` / ``up`` / ``down`` with the first two :class:`TorchFP4Linear` of equal shape, activation ``act`` a SiLU) by a
+    :class:`FusedGatedMLP`.  Single-token calls then pay one launch for gate + up + activation + product instead of four; other
+    shapes run the unfused sequence.  Returns how many were replaced.  Not in the reference (its surface stops at the Linear)."""
+    count = 0
+    for name, child in list(module.named_children()):
+        g, u, d, a = (getattr(child, n, None) for n in (gate, up, down, act))
+        silu = isinstance(a, nn.SiLU) or "silu" in type(a).__name__.lower() or a is nn.functional.silu
+        if (isinstance(g, TorchFP4Linear) and isinstance(u, TorchFP4Linear) and isinstance(d, nn.Module) and silu
+                and (g.quant_data.M, g.quant_data.N, g.quant_data.blocksize) == (u.quant_data.M, u.quant_data.N, u.quant_data.blocksize)
+                ):
+            module._modules[name] = FusedGatedMLP(g, u, d)
+            count += 1
+        else:
+            count += fuse_gated_mlps(child, gate, up, down, act)
+    return count
