@@ -224,6 +224,61 @@ def c5_leg(dist, backend, rank, world, dev, barrier, tokens=16):
     return out
 
 
+def fused_epilogue_leg(lib, dev):
+    """us per launch of fp4_hip_gemv_fused at Mistral-7B / Llama-3-8B layer shapes, HBM-cold rotation, HIP-graph replay."""
+    vp, i32, i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
+    lib.l.fp4_hip_gemv_fused.argtypes = [vp, vp, vp, vp, vp, vp, i64, i64, i32, i32, i32, vp]
+    out = {}
+    for name, (m, k), epi in (("o_plus_residual_4096x4096", (4096, 4096), 0), ("gate_up_silu_mul_28672x4096", (28672, 4096), 1),
+                              ("down_plus_residual_4096x14336", (4096, 14336), 0)):
+        n = m * k
+        r = max(8, min(32, int(1.0e9 / (n * 0.5625))))
+        gen = torch.Generator(device=dev).manual_seed(5)
+        packed = [torch.randint(0, 256, (n // 2,), dtype=torch.uint8, device=dev, generator=gen) for _ in range(r)]
+        absmax = [torch.rand(n // BLOCKSIZE, device=dev, generator=gen) * 0.02 + 0.002 for _ in range(r)]
+        x = torch.randn(k, device=dev).to(torch.bfloat16)
+        m_out = m // 2 if epi else m
+        res = torch.randn(m_out, device=dev).to(torch.bfloat16)
+        y = torch.empty(m_out, dtype=torch.bfloat16, device=dev)
+
+        def run():
+            s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+            for i in range(r):
+                lib._check(lib.l.fp4_hip_gemv_fused(x.data_ptr(), packed[i].data_ptr(), absmax[i].data_ptr(), None, res.data_ptr(),
+                                                    y.data_ptr(), m, k, BLOCKSIZE, BF16, epi, s))
+
+        def plain():
+            for i in range(r):
+                lib.gemv(x, packed[i], absmax[i], yp, m, k)
+
+        yp = torch.empty(m, dtype=torch.bfloat16, device=dev)
+        out[name] = round(time_replays(capture(run), 5, r)[0], 3)
+        out[name.split("_")[0] + "_plain_gemv_same_weight"] = round(time_replays(capture(plain), 5, r)[0], 3)
+        del packed, absmax
+    return out
+
+
+def c4_leg(dev, tokens=24):
+    """Outside the timed region: ms per token of batch-1 decode through 32 Mistral-7B shaped layers (+ dense lm_head), replayed
+    from a HIP graph, as separate launches, with q|k|v and gate|up row-concatenated, and with the fused epilogues."""
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import decode_bench as db
+
+    cfg = dict(db.MODELS["mistral7b"])
+    cfg["layers"] = int(os.environ.get("FP4_BENCH_C4_LAYERS", cfg["layers"]))
+    out = {"model": "mistral7b shapes", "layers": cfg["layers"], "dtype": "bf16",
+           "note": "synthetic FP4 bytes; attention replaced by identity; lm_head dense bf16; HIP-graph replay"}
+    for name, kw in (("separate_launches", {}), ("row_concat", {"fuse": True}), ("row_concat_plus_epilogues", {"epilogues": True})):
+        token, h0, meta = db.build_token_fn(cfg, dev, torch.bfloat16, **kw)
+        t = db.time_tokens(token, h0, tokens, graph=True)
+        out[name] = {"graph_ms_per_token": None if t["graph_s"] is None else round(t["graph_s"] * 1e3, 3),
+                     "eager_ms_per_token": round(t["eager_s"] * 1e3, 3), "fp4_launches_per_token": meta["fp4_linear_calls_per_token"]}
+        out["hbm_floor_ms_per_token_at_8TBps"] = round((meta["fp4_bytes_per_token_per_gpu"] + meta["lm_head_bytes"]) / 8e12 * 1e3, 3)
+        del token, h0
+        torch.cuda.empty_cache()
+    return out
+
+
 def capture(fn):
     """Capture fn() into a HIP graph (after one eager run) and return a replay callable."""
     fn()
@@ -480,6 +535,18 @@ def main():
             us = time_replays(cp, 5, 1)[0]
             extra["device_copy_gbps"] = round(2 * src.numel() / us / 1e3, 1)
             del src, dst
+            # the fused decode epilogues at the layer shapes they serve (HBM-cold like the headline): h + o(a), silu(g)*u over the
+            # interleaved gate|up weight, h + down(act); same weight traffic as the plain GEMV of that shape
+            try:
+                extra["fused_epilogue_us"] = fused_epilogue_leg(lib, dev)
+            except Exception as exc:
+                extra["fused_epilogue_us"] = {"error": repr(exc)[:200]}
+            # BASELINE config 4 (driver-visible): batch-1 decode through every FP4 Linear of a Mistral-7B shaped model
+            if world == 1 and os.environ.get("FP4_BENCH_C4", "1") == "1":
+                try:
+                    extra["c4_mistral7b_decode"] = c4_leg(dev)
+                except Exception as exc:
+                    extra["c4_mistral7b_decode"] = {"error": repr(exc)[:300]}
 
     times = torch.tensor([wall, dq_total_s, gv_total_s], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     if world > 1:

@@ -26,11 +26,15 @@ def _run(args, env_extra):
 
 
 def test_single_gpu_line_schema():
-    rec = _run(["--steps", "2", "--warmup", "1", "--matrices", "8", "--no-cpu"], {})
+    rec = _run(["--steps", "2", "--warmup", "1", "--matrices", "8", "--no-cpu"], {"FP4_BENCH_C4_LAYERS": "2"})
     assert SCHEMA <= set(rec) and rec["n_gpus"] == 1 and rec["steps"] == 2 and rec["unit"] == "GB/s" and rec["dtype"] == "bf16"
     r = rec["roofline"]
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert 0.2 < r["frac"] < 1.0 and "workload" in rec["config"] and "model" not in rec["config"]
+    # driver-visible secondary legs (outside the timed region): fused epilogues at layer shapes, config C4 in three forms
+    fe, c4 = rec["fused_epilogue_us"], rec["c4_mistral7b_decode"]
+    assert "error" not in fe and fe["gate_up_silu_mul_28672x4096"] > 0 and "error" not in c4, (fe, c4)
+    assert c4["row_concat_plus_epilogues"]["graph_ms_per_token"] < c4["separate_launches"]["graph_ms_per_token"]
 
 
 def test_two_ranks_self_launched_over_gloo():
