@@ -201,7 +201,7 @@ def c5_leg(dist, backend, rank, world, dev, barrier, tokens=16):
             out["oneshot_selfcheck"] = {"ok": False, "error": repr(exc)[:300]}
     for ar, graph in modes:
         try:
-            token, h0, meta = db.build_token_fn(cfg, dev, torch.bfloat16, world, rank, allreduce=ar, lm_head=False)
+            token, h0, meta = db.build_token_fn(cfg, dev, torch.bfloat16, world, rank, allreduce=ar, lm_head=False, epilogues=True)
             t = db.time_tokens(token, h0, tokens, graph=graph, barrier=barrier)
             best = t["graph_s"] or t["eager_s"]
             out[ar] = {"eager_ms_per_token": round(t["eager_s"] * 1e3, 3),
@@ -219,8 +219,9 @@ def c5_leg(dist, backend, rank, world, dev, barrier, tokens=16):
         except Exception as exc:
             out[ar] = {"error": repr(exc)[:300]}
         torch.cuda.empty_cache()
-    out["note"] = ("2 all-reduces of 16 KiB f32 per layer; latency-bound; eager launches are host-bound; attention replaced by "
-                   "identity, lm_head left out")
+    out["note"] = ("q|k|v shards in one launch, gate|up shards interleaved with silu(g)*u in the epilogue, residual adds inside the "
+                   "K-split layers; 2 all-reduces of 16 KiB f32 per layer (latency-bound); eager launches are host-bound; attention "
+                   "replaced by identity, lm_head left out")
     return out
 
 

@@ -62,12 +62,13 @@ def _worker(rank, world, port, out_q):
         sys.path[:0] = [here]
         import torch_bnb_fp4 as pkg
         from fake_ext import FakeExt
-        from torch_bnb_fp4 import functional as F_mod, parallel as par, quant_data as qd_mod
+        from torch_bnb_fp4 import functional as F_mod, fused as fused_mod, parallel as par, quant_data as qd_mod
 
         fake = FakeExt(pkg.ext)
         F_mod.ext = fake
         qd_mod.ext = fake
         par.ext = fake
+        fused_mod.ext = fake
         packed, am, bias, x = _case()
         P, A, B = torch.from_numpy(packed).view(-1, 1), torch.from_numpy(am), torch.from_numpy(bias)
         xt = torch.from_numpy(x)
@@ -78,6 +79,20 @@ def _worker(rank, world, port, out_q):
             "colN": col(torch.stack([xt, 2 * xt])), "rowN": row(torch.stack([xt, 2 * xt])),
             "calls": list(fake.calls),
         }
+        # the fused tensor-parallel forms: several M-split projections in one launch per rank, gate|up with silu(g)*u fused
+        xb = xt.to(torch.bfloat16).view(1, K)
+        col_ng = par.ColumnParallelFP4Linear(P, A, (M, K), BS, gather_output=False)
+        P2 = torch.flip(P, dims=[0]).contiguous()
+        col2_ng = par.ColumnParallelFP4Linear(P2, A, (M, K), BS, gather_output=False)
+        qkv = par.FusedColumnParallelFP4([(P, A, (M, K)), (P2, A, (M, K)), (P, A, (M, K))], BS)
+        ya, yb = col_ng(xb), col2_ng(xb)
+        res["fused_cat_equal"] = bool(torch.equal(qkv(xb), torch.cat([ya, yb, ya], dim=-1))) and qkv.split_sizes == [M // world] * 3
+        gu = par.FusedColumnParallelFP4([(P, A, (M, K)), (P2, A, (M, K))], BS, epilogue="silu_mul")
+        want = torch.nn.functional.silu(ya) * yb
+        got = gu(xb)
+        res["fused_silu_shape"] = tuple(got.shape) == (1, M // world)
+        res["fused_silu_close"] = float((got.float() - want.float()).abs().max()) <= 0.02 * float(want.float().abs().max()) + 1e-3
+        res["row_residual"] = row(xt.view(1, K), residual=torch.ones(1, M))
         if rank == 0:
             out_q.put({k: (v.numpy() if isinstance(v, torch.Tensor) else v) for k, v in res.items()})
         dist.barrier()
@@ -104,3 +119,5 @@ def test_column_and_row_parallel_world2_gloo():
         assert res[key].shape == (2, M)
         assert np.allclose(res[key][0], want, rtol=1e-3, atol=1e-4) and np.allclose(res[key][1], 2 * want - bias, rtol=1e-3, atol=1e-4)
     assert "gemv_fp4_partial" in res["calls"] and "gemv_fp4_bias" in res["calls"]
+    assert res["fused_cat_equal"] and res["fused_silu_shape"] and res["fused_silu_close"]
+    assert np.allclose(res["row_residual"].reshape(-1), want + 1.0, rtol=1e-4, atol=1e-5)

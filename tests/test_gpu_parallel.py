@@ -76,6 +76,19 @@ def _worker(rank, world, port, q):
                 torch.cuda.synchronize()
                 ok = ok and torch.equal(y_static, row(static_x))
             r["graph_equal"] = ok
+            # fused tensor-parallel forms on the real kernels: q|k|v-style shards in one launch (bit-identical to separate
+            # column-parallel layers), gate|up shards interleaved with silu(g)*u in the epilogue (<= 1 ulp of the separate ops)
+            col_ng = par.ColumnParallelFP4Linear(P, A, (M, K), BS, gather_output=False)
+            P2 = torch.flip(P, dims=[0]).contiguous()
+            col2_ng = par.ColumnParallelFP4Linear(P2, A, (M, K), BS, gather_output=False)
+            x1 = xt.view(1, K)
+            ya, yb = col_ng(x1), col2_ng(x1)
+            fz = par.FusedColumnParallelFP4([(P, A, (M, K)), (P2, A, (M, K)), (P, A, (M, K))], BS)
+            r["fused_cat_equal"] = bool(torch.equal(fz(x1), torch.cat([ya, yb, ya], dim=-1)))
+            gu = par.FusedColumnParallelFP4([(P, A, (M, K)), (P2, A, (M, K))], BS, epilogue="silu_mul")
+            d = (gu(x1).view(torch.int16).int() - (torch.nn.functional.silu(ya) * yb).view(torch.int16).int()).abs()
+            r["fused_silu_max_ulp"] = int(d.max().item())
+            r["fused_silu_exact_share"] = float((d == 0).float().mean().item())
             res[(M, K)] = {k: (v.float().cpu().numpy() if isinstance(v, torch.Tensor) else v) for k, v in r.items()}
         comm = par.oneshot_comm(None)
         comm.check()
@@ -133,6 +146,7 @@ def test_tensor_parallel_two_ranks_on_one_gpu():
         # one-shot vs torch.distributed: identical bits (two ranks: a + b in either order)
         assert np.array_equal(r["one1"], r["row1"]) and np.array_equal(r["one4"], r["row4"])
         assert r["seq_equal"] and r["graph_equal"]
+        assert r["fused_cat_equal"] and r["fused_silu_max_ulp"] <= 1 and r["fused_silu_exact_share"] >= 0.998, r
     assert res["status"][2] == 0 and res["status"][3] == 0 and res["status"][1] == 0, res["status"]
     assert res["memory_kind"] in ("uncached", "fine-grained", "default")
     assert "timed out waiting for rank 1" in res["timeout"] and res["timeout_nan"], res["timeout"]

@@ -86,6 +86,14 @@ def build_token_fn(cfg, dev, dtype, world=1, rank=0, group=None, fuse=False, epi
         elif fuse and world == 1:
             ly = dict(qkv=linear([H, KV, KV], H, "col"), o=linear(H, H, "row"), gate_up=linear([I, I], H, "col"),
                       down=linear(H, I, "row"))
+        elif (fuse or epilogues) and world > 1:
+            # tensor parallel with the same fusions: q|k|v shards in one launch, gate|up shards interleaved with silu(g)*u in the
+            # epilogue, the residual adds inside the K-split layers (in the one-shot all-reduce's epilogue when that is used)
+            w = lambda m, k: (*fp4_weight(m, k), (m, k))
+            ly = dict(tp_qkv=par.FusedColumnParallelFP4([w(H, H), w(KV, H), w(KV, H)], BS, group),
+                      o=linear(H, H, "row"),
+                      tp_gate_up=par.FusedColumnParallelFP4([w(I, H), w(I, H)], BS, group, epilogue="silu_mul"),
+                      down=linear(H, I, "row"))
         else:
             ly = dict(q=linear(H, H, "col"), k=linear(KV, H, "col"), v=linear(KV, H, "col"), o=linear(H, H, "row"),
                       gate=linear(I, H, "col"), up=linear(I, H, "col"), down=linear(H, I, "row"))
@@ -96,6 +104,12 @@ def build_token_fn(cfg, dev, dtype, world=1, rank=0, group=None, fuse=False, epi
 
     def token(h):
         for ly in layers:
+            if "tp_qkv" in ly:
+                q, k, v = ly["tp_qkv"](h).split(ly["tp_qkv"].split_sizes, dim=-1)
+                a = q + 0.0 * (k.sum() + v.sum())
+                h = ly["o"](a.contiguous(), residual=h)
+                h = ly["down"](ly["tp_gate_up"](h), residual=h) * 0.5
+                continue
             if "gate_up" in ly and epilogues and world == 1:
                 q, k, v = ly["qkv"](h).split([H, KV, KV], dim=-1)
                 a = q + 0.0 * (k.sum() + v.sum())
@@ -118,7 +132,7 @@ def build_token_fn(cfg, dev, dtype, world=1, rank=0, group=None, fuse=False, epi
 
     per_token_fp4 = L * (2 * fp4_bytes(H, H) + 2 * fp4_bytes(KV, H) + 2 * fp4_bytes(I, H) + fp4_bytes(H, I)) // world
     meta = dict(layers=L, fp4_bytes_per_token_per_gpu=per_token_fp4, lm_head_bytes=(V * H * 2 if lm_head else 0),
-                fp4_linear_calls_per_token=(4 if ((fuse or epilogues) and world == 1) else 7) * L,
+                fp4_linear_calls_per_token=(4 if (fuse or epilogues) else 7) * L,
                 allreduces_per_token=(2 * L if world > 1 else 0))
     return token, h0, meta
 

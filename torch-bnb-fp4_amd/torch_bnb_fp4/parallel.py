@@ -124,6 +124,37 @@ class ColumnParallelFP4Linear(nn.Module):
         return _all_gather_last(y, self.world, self.group)
 
 
+class FusedColumnParallelFP4(nn.Module):
+    """Several M-split projections that share their input as ONE launch per rank (q|k|v, or gate|up with the activation in
+    the epilogue): each weight is row-sharded first, then this rank's shards are row-concatenated (or, for ``silu_mul``,
+    row-interleaved), so the local output is ``cat([W_i[shard] x])`` - the same values the separate column-parallel layers
+    would give, without a gather.  ``split_sizes`` are the local output widths."""
+
+    def __init__(self, weights, blocksize: int = 64, group=None, epilogue: Optional[str] = None):
+        super().__init__()
+        from .fused import EPILOGUE_NONE, EPILOGUE_SILU_MUL_PAIRS, FusedFP4Linear, interleave_rows
+
+        self.group = group
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        shards = [shard_rows(p, a, shp, blocksize, self.rank, self.world) for p, a, shp in weights]
+        if epilogue == "silu_mul":
+            if len(shards) != 2 or shards[0][2] != shards[1][2]:
+                raise ValueError("silu_mul needs exactly a gate and an up projection of the same shape")
+            packed, absmax, local = interleave_rows((shards[0][0], shards[0][1]), (shards[1][0], shards[1][1]), shards[0][2], blocksize)
+            self.layer = FusedFP4Linear.from_packed(packed, absmax, local, blocksize, None, EPILOGUE_SILU_MUL_PAIRS)
+            self.split_sizes = [shards[0][2][0]]
+        elif epilogue is None:
+            packed, absmax, local = concat_rows(shards, blocksize)
+            self.layer = FusedFP4Linear.from_packed(packed, absmax, local, blocksize, None, EPILOGUE_NONE)
+            self.split_sizes = [s[2][0] for s in shards]
+        else:
+            raise ValueError(f"unknown epilogue {epilogue!r}")
+        self.in_features = int(weights[0][2][1])
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return self.layer(x)
+
+
 class RowParallelFP4Linear(nn.Module):
     """K-split: this rank owns ``in_features / world`` columns; outputs are summed across ranks in f32."""
 
