@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FP4_HIP_ABI_VERSION 4
+#define FP4_HIP_ABI_VERSION 5
 #define FP4_HIP_API __attribute__((visibility("default")))
 
 /* Element types, numbered like the reference's ScalarTypeEnum (csrc/torch_fp4.cpp:22-26). */
@@ -124,6 +124,18 @@ FP4_HIP_API int fp4_hip_gemv_fused(const void *x, const uint8_t *packed, const f
  */
 FP4_HIP_API int fp4_hip_gemm_small(const void *x, const uint8_t *packed, const float *absmax, const void *bias, void *out,
                                    int64_t B, int64_t M, int64_t K, int blocksize, int dtype, void *stream);
+
+/*
+ * The small-batch product with the fused decode epilogues of fp4_hip_gemv_fused, for 1..64 activation rows (batched decode):
+ *   EPILOGUE_NONE:            t = T(sum[b][r] + bias[r]) (F.linear: bias in f32, one rounding); if residual: t = T(t + residual[b][r])
+ *                             out : T[B, M], residual : T[B, M].
+ *   EPILOGUE_SILU_MUL_PAIRS:  rows interleave gate and up (row 2i / 2i+1): g = T(sum_2i + bias_2i), u = T(sum_2i+1 + bias_2i+1),
+ *                             t = T(T(silu(g)) * u); if residual: t = T(t + residual[b][i]);  out, residual : T[B, M/2], M even.
+ * Same shape coverage and FP4_ERR_UNSUPPORTED behaviour as fp4_hip_gemm_small.  Not in the reference.
+ */
+FP4_HIP_API int fp4_hip_gemm_small_fused(const void *x, const uint8_t *packed, const float *absmax, const void *bias,
+                             const void *residual, void *out, int64_t B, int64_t M, int64_t K, int blocksize, int dtype,
+                             int epilogue, void *stream);
 
 /*
  * K-split (row-parallel) building block: the same GEMV, but the f32 accumulator is written as is

@@ -72,6 +72,20 @@ class FakeExt:
             t = o.linear_epilogue(y, _NP[A.dtype], nb, nr)
         return torch.from_numpy(np.asarray(t, np.float32)).to(A.dtype).view(*A.shape[:-1], -1)
 
+    def gemm_small_fp4_fused(self, A, B, absmax, blocksize, Bshape, bias, residual, epilogue):
+        self.calls.append("gemm_small_fp4_fused")
+        M, K = Bshape
+        w = o.dequantize_f32(B.numpy().reshape(-1), absmax.numpy(), blocksize, M * K).reshape(M, K).astype(np.float64)
+        y = A.float().numpy().reshape(-1, K).astype(np.float64) @ w.T
+        if bias is not None:
+            y = y + bias.float().numpy().astype(np.float64)
+        nr = None if residual is None else residual.float().numpy().reshape(y.shape[0], -1)
+        if epilogue == 1:
+            t = o.silu_mul_epilogue(y[:, 0::2], y[:, 1::2], _NP[A.dtype], nr)
+        else:
+            t = o.linear_epilogue(y, _NP[A.dtype], None, nr)
+        return torch.from_numpy(np.asarray(t, np.float32)).to(A.dtype).view(*A.shape[:-1], -1)
+
     def gemm_small_fp4(self, A, B, absmax, blocksize, Bshape, bias):
         self.calls.append("gemm_small_fp4")
         M, K = Bshape

@@ -40,6 +40,8 @@ def lib():
         l.fp4_hip_gemv_partial.argtypes = [vp, vp, vp, vp, i64, i64, i32, i32, vp]
         l.fp4_hip_gemv_fused.argtypes = [vp, vp, vp, vp, vp, vp, i64, i64, i32, i32, i32, vp]
         l.fp4_hip_gemv_fused.restype = i32
+        l.fp4_hip_gemm_small_fused.argtypes = [vp, vp, vp, vp, vp, vp, i64, i64, i64, i32, i32, i32, vp]
+        l.fp4_hip_gemm_small_fused.restype = i32
         l.fp4_hip_gemm_small.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, i32, i32, vp]
         l.fp4_hip_gemm_small.restype = i32
         l.fp4_hip_quantize_blockwise.argtypes = [vp, i32, vp, vp, i64, i32, vp]
@@ -104,6 +106,19 @@ def gemm_small(x: torch.Tensor, packed: torch.Tensor, absmax: torch.Tensor, M: i
     B = x.numel() // K
     out = torch.empty(B, M, dtype=x.dtype, device=x.device)
     rc = lib().fp4_hip_gemm_small(_ptr(x), _ptr(packed), _ptr(absmax), _ptr(bias), _ptr(out), B, M, K, blocksize, DT[x.dtype], _stream())
+    if expect_ok:
+        assert rc == OK, (rc, last_error())
+        return out
+    return rc
+
+
+def gemm_small_fused(x: torch.Tensor, packed: torch.Tensor, absmax: torch.Tensor, M: int, K: int, blocksize: int,
+                     bias: torch.Tensor | None = None, residual: torch.Tensor | None = None, epilogue: int = EPILOGUE_NONE,
+                     expect_ok: bool = True):
+    B = x.numel() // K
+    out = torch.empty(B, M // 2 if epilogue == EPILOGUE_SILU_MUL_PAIRS else M, dtype=x.dtype, device=x.device)
+    rc = lib().fp4_hip_gemm_small_fused(_ptr(x), _ptr(packed), _ptr(absmax), _ptr(bias), _ptr(residual), _ptr(out), B, M, K, blocksize,
+                                        DT[x.dtype], epilogue, _stream())
     if expect_ok:
         assert rc == OK, (rc, last_error())
         return out

@@ -175,12 +175,16 @@ def test_fused_layers_dispatch_and_fall_back(fake, monkeypatch):
     u64 = o.gemv_exact(x.float().numpy().reshape(-1), pu, au, M, K, 64)
     want = o.silu_mul_epilogue(g64, u64, "bfloat16")
     assert np.array_equal(y.float().numpy().reshape(-1), want)
-    # a batch runs the unfused sequence (de-interleaving the rows), same meaning
+    # 2..32 rows: the same epilogue on the small-batch kernels; more rows: the unfused sequence (de-interleaving the rows)
     fake.calls.clear()
     xb = torch.cat([x, x])
     yb = gu(xb)
-    assert "gemv_fp4_fused" not in fake.calls and yb.shape == (2, M)
+    assert fake.calls == ["gemm_small_fp4_fused"] and yb.shape == (2, M)
     assert (yb[0].float() - y[0].float()).abs().max() <= 0.05 * max(1.0, y.float().abs().max().item())
+    fake.calls.clear()
+    y40 = gu(x.repeat(40, 1))
+    assert "gemm_small_fp4_fused" not in fake.calls and "gemv_fp4_fused" not in fake.calls and y40.shape == (40, M)
+    assert (y40[7].float() - y[0].float()).abs().max() <= 0.05 * max(1.0, y.float().abs().max().item())
     # plain layer: residual in the epilogue for one token, added separately for a batch
     dn = fused.FusedFP4Linear.from_packed(*tg, (M, K), 64)
     r = torch.randn(1, M).to(torch.bfloat16)

@@ -24,8 +24,8 @@ std::atomic<int> g_small_variant{-1};  // -1 heuristic, 0 VALU kernel, 1 matrix-
 template <int DT, int KSPLIT, int G, int ITERS, int NB>
 __global__ __launch_bounds__(256) void gemm16_small_kernel(const uint16_t *__restrict__ x, const uint8_t *__restrict__ W,
                                                            const float *__restrict__ absmax,
-                                                           const uint16_t *__restrict__ bias, uint16_t *__restrict__ out,
-                                                           int B, int M, int K, int bs_shift) {
+                                                           const uint16_t *__restrict__ bias, const uint16_t *residual, uint16_t *out,
+                                                           int B, int M, int K, int bs_shift, int mode) {
     constexpr int RG = 4 / KSPLIT;
     constexpr int kRowsPerBlock = 2 * RG * ITERS;
     __shared__ float s_part[kRowsPerBlock][KSPLIT][NB];
@@ -131,9 +131,15 @@ __global__ __launch_bounds__(256) void gemm16_small_kernel(const uint16_t *__res
         for (int k = 0; k < KSPLIT; ++k) t += s_part[r][k][b];
         const int row = row_base + r;
         if (row < M && b < B) {
-            t *= (1.0f / 12.0f);
-            if (bias) t += to_f32<DT>(bias[row]);
-            out[int64_t(b) * M + row] = from_f32<DT>(t);
+            if (mode & kModeSiluMulPairs) {  // rows (r, r + 1) of this workgroup = (gate, up) of one pair; row_base is even
+                if (r & 1) continue;
+                float u = 0.0f;
+#pragma unroll
+                for (int k = 0; k < KSPLIT; ++k) u += s_part[r + 1][k][b];
+                store_small_silu_mul<DT>(out, bias, residual, b, row >> 1, M >> 1, t * (1.0f / 12.0f), u * (1.0f / 12.0f));
+            } else {
+                store_small<DT>(out, bias, residual, b, row, M, t * (1.0f / 12.0f));
+            }
         }
     }
 }
@@ -175,8 +181,8 @@ __device__ __forceinline__ u32x4 pair_up8(u32x4 w) {
 template <int DT, int NBW, int ROWT, bool STAGE, int XS = 0>
 __global__ __launch_bounds__(512) void gemm16_mfma_kernel(const uint16_t *__restrict__ x, const uint8_t *__restrict__ W,
                                                           const float *__restrict__ absmax,
-                                                          const uint16_t *__restrict__ bias, uint16_t *__restrict__ out,
-                                                          int B, int M, int K) {
+                                                          const uint16_t *__restrict__ bias, const uint16_t *residual, uint16_t *out,
+                                                          int B, int M, int K, int mode) {
     // ROWT 16-row tiles per workgroup share one B fragment (x slice): x is re-read by every workgroup, so taller
     // workgroups cut that L2 traffic (B*K*2 bytes each) at the price of fewer workgroups
     // STAGE: the A-fragment layout wants 8 bytes per lane from 16 different rows (32-byte segments per row per
@@ -392,9 +398,15 @@ __global__ __launch_bounds__(512) void gemm16_mfma_kernel(const uint16_t *__rest
         const int l = e >> 2, reg = e & 3;  // D layout: col = l & 15 (activation row), row = (l >> 4) * 4 + reg (weight row)
         const int n = l & 15, row = row0 + 16 * rt + (l >> 4) * 4 + reg;
         if (row < M && n < B) {
-            t *= (1.0f / 12.0f);
-            if (bias) t += to_f32<DT>(bias[row]);
-            out[int64_t(n) * M + row] = from_f32<DT>(t);
+            if (mode & kModeSiluMulPairs) {  // registers (0, 1) and (2, 3) of a lane hold the (gate, up) rows of one pair
+                if (reg & 1) continue;
+                float u = 0.0f;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) u += s_part[w][rt][e + 1];
+                store_small_silu_mul<DT>(out, bias, residual, n, row >> 1, M >> 1, t * (1.0f / 12.0f), u * (1.0f / 12.0f));
+            } else {
+                store_small<DT>(out, bias, residual, n, row, M, t * (1.0f / 12.0f));
+            }
         }
     }
 }
@@ -408,8 +420,8 @@ __global__ __launch_bounds__(512) void gemm16_mfma_kernel(const uint16_t *__rest
 template <int DT, int XS>
 __global__ __launch_bounds__(512) void gemm16_mfma_persist_kernel(const uint16_t *__restrict__ x, const uint8_t *__restrict__ W,
                                                                   const float *__restrict__ absmax,
-                                                                  const uint16_t *__restrict__ bias, uint16_t *__restrict__ out,
-                                                                  int B, int M, int K, int ntiles) {
+                                                                  const uint16_t *__restrict__ bias, const uint16_t *residual,
+                                                                  uint16_t *out, int B, int M, int K, int ntiles, int mode) {
     constexpr int NBW = 8;
     constexpr int kStageStride = 32 * NBW + 32, kXStride = 128 * NBW + 16;
     constexpr int kXUnits = XS ? XS * NBW / 8 : 1;
@@ -534,9 +546,16 @@ __global__ __launch_bounds__(512) void gemm16_mfma_persist_kernel(const uint16_t
             const int l = tid >> 2, reg = tid & 3;  // D layout: col = l & 15 (activation row), row = (l >> 4) * 4 + reg
             const int n = l & 15, row = tile * 16 + (l >> 4) * 4 + reg;
             if (row < M && n < B) {
-                t *= (1.0f / 12.0f);
-                if (bias) t += to_f32<DT>(bias[row]);
-                out[int64_t(n) * M + row] = from_f32<DT>(t);
+                if (mode & kModeSiluMulPairs) {
+                    if (!(reg & 1)) {
+                        float u = 0.0f;
+#pragma unroll
+                        for (int w = 0; w < 8; ++w) u += s_part[w][tid + 1];
+                        store_small_silu_mul<DT>(out, bias, residual, n, row >> 1, M >> 1, t * (1.0f / 12.0f), u * (1.0f / 12.0f));
+                    }
+                } else {
+                    store_small<DT>(out, bias, residual, n, row, M, t * (1.0f / 12.0f));
+                }
             }
         }
         __syncthreads();  // s_part is rewritten by the next tile
@@ -552,8 +571,8 @@ std::atomic<int> g_mfma_persist{-1};  // 0 = never the persistent kernel, 1 = wh
 std::atomic<int> g_mfma_nbw4{-1};     // 1 = at most 4 blocks per wave and pass (pass-ahead loads), 0 = 8 wherever they divide K
 
 template <int DT>
-int dispatch_mfma(const void *x, const uint8_t *W, const float *absmax, const void *bias, void *out, int B, int M, int K,
-                  hipStream_t stream) {
+int dispatch_mfma(const void *x, const uint8_t *W, const float *absmax, const void *bias, const void *residual, void *out, int B, int M,
+                  int K, int mode, hipStream_t stream) {
     if (K % 512) return -1;
     const int units = K / 512;  // quant blocks per wave over the whole K
     const int v_rowt = g_mfma_rowt.load(std::memory_order_relaxed), v_stage = g_mfma_stage.load(std::memory_order_relaxed),
@@ -575,15 +594,15 @@ int dispatch_mfma(const void *x, const uint8_t *W, const float *absmax, const vo
             if (B <= 4)
                 hipLaunchKernelGGL((gemm16_mfma_persist_kernel<DT, 4>), grid, dim3(512), 0, stream,
                                    reinterpret_cast<const uint16_t *>(x), W, absmax, reinterpret_cast<const uint16_t *>(bias),
-                                   reinterpret_cast<uint16_t *>(out), B, M, K, ntiles);
+                                   reinterpret_cast<const uint16_t *>(residual), reinterpret_cast<uint16_t *>(out), B, M, K, ntiles, mode);
             else if (B <= 8)
                 hipLaunchKernelGGL((gemm16_mfma_persist_kernel<DT, 8>), grid, dim3(512), 0, stream,
                                    reinterpret_cast<const uint16_t *>(x), W, absmax, reinterpret_cast<const uint16_t *>(bias),
-                                   reinterpret_cast<uint16_t *>(out), B, M, K, ntiles);
+                                   reinterpret_cast<const uint16_t *>(residual), reinterpret_cast<uint16_t *>(out), B, M, K, ntiles, mode);
             else
                 hipLaunchKernelGGL((gemm16_mfma_persist_kernel<DT, 0>), grid, dim3(512), 0, stream,
                                    reinterpret_cast<const uint16_t *>(x), W, absmax, reinterpret_cast<const uint16_t *>(bias),
-                                   reinterpret_cast<uint16_t *>(out), B, M, K, ntiles);
+                                   reinterpret_cast<const uint16_t *>(residual), reinterpret_cast<uint16_t *>(out), B, M, K, ntiles, mode);
             return FP4_OK;
         }
     }
@@ -593,26 +612,26 @@ int dispatch_mfma(const void *x, const uint8_t *W, const float *absmax, const vo
     if (v_stage == 0) {                                                                                          \
         hipLaunchKernelGGL((gemm16_mfma_kernel<DT, NBW, RT, false>), dim3(blocks), dim3(512), 0, stream,              \
                            reinterpret_cast<const uint16_t *>(x), W, absmax, reinterpret_cast<const uint16_t *>(bias), \
-                           reinterpret_cast<uint16_t *>(out), B, M, K);                                               \
+                           reinterpret_cast<const uint16_t *>(residual), reinterpret_cast<uint16_t *>(out), B, M, K, mode);                                               \
         return FP4_OK;                                                                                                \
     }                                                                                                                 \
     if constexpr ((NBW) >= 4) {                                                                                       \
         if (xs4) {                                                                                                    \
             hipLaunchKernelGGL((gemm16_mfma_kernel<DT, NBW, RT, true, 4>), dim3(blocks), dim3(512), 0, stream,        \
                                reinterpret_cast<const uint16_t *>(x), W, absmax,                                      \
-                               reinterpret_cast<const uint16_t *>(bias), reinterpret_cast<uint16_t *>(out), B, M, K); \
+                               reinterpret_cast<const uint16_t *>(bias), reinterpret_cast<const uint16_t *>(residual), reinterpret_cast<uint16_t *>(out), B, M, K, mode); \
             return FP4_OK;                                                                                            \
         }                                                                                                             \
         if (xs8) {                                                                                                    \
             hipLaunchKernelGGL((gemm16_mfma_kernel<DT, NBW, RT, true, 8>), dim3(blocks), dim3(512), 0, stream,        \
                                reinterpret_cast<const uint16_t *>(x), W, absmax,                                      \
-                               reinterpret_cast<const uint16_t *>(bias), reinterpret_cast<uint16_t *>(out), B, M, K); \
+                               reinterpret_cast<const uint16_t *>(bias), reinterpret_cast<const uint16_t *>(residual), reinterpret_cast<uint16_t *>(out), B, M, K, mode); \
             return FP4_OK;                                                                                            \
         }                                                                                                             \
     }                                                                                                                 \
     hipLaunchKernelGGL((gemm16_mfma_kernel<DT, NBW, RT, true>), dim3(blocks), dim3(512), 0, stream,                   \
                        reinterpret_cast<const uint16_t *>(x), W, absmax, reinterpret_cast<const uint16_t *>(bias),    \
-                       reinterpret_cast<uint16_t *>(out), B, M, K);                                                   \
+                       reinterpret_cast<const uint16_t *>(residual), reinterpret_cast<uint16_t *>(out), B, M, K, mode);                                                   \
     return FP4_OK
 #define FP4_MF_RT(NBW)          \
     if (rowt == 2) {            \
@@ -631,23 +650,23 @@ int dispatch_mfma(const void *x, const uint8_t *W, const float *absmax, const vo
 }
 
 template <int DT, int KSPLIT, int G, int ITERS, int NB>
-int launch_small(const void *x, const uint8_t *W, const float *absmax, const void *bias, void *out, int B, int M, int K,
-                 int bs_shift, hipStream_t stream) {
+int launch_small(const void *x, const uint8_t *W, const float *absmax, const void *bias, const void *residual, void *out, int B, int M,
+                 int K, int bs_shift, int mode, hipStream_t stream) {
     constexpr int rows_per_block = 2 * (4 / KSPLIT) * ITERS;
     const unsigned blocks = (unsigned)((M + rows_per_block - 1) / rows_per_block);
     hipLaunchKernelGGL((gemm16_small_kernel<DT, KSPLIT, G, ITERS, NB>), dim3(blocks), dim3(256), 0, stream,
                        reinterpret_cast<const uint16_t *>(x), W, absmax, reinterpret_cast<const uint16_t *>(bias),
-                       reinterpret_cast<uint16_t *>(out), B, M, K, bs_shift);
+                       reinterpret_cast<const uint16_t *>(residual), reinterpret_cast<uint16_t *>(out), B, M, K, bs_shift, mode);
     return FP4_OK;
 }
 
 // returns -1 when the shape is outside what the register budget covers (caller falls back to dequant + GEMM)
 template <int DT>
-int dispatch_small(const void *x, const uint8_t *W, const float *absmax, const void *bias, void *out, int B, int M, int K,
-                   int bs_shift, hipStream_t stream) {
+int dispatch_small(const void *x, const uint8_t *W, const float *absmax, const void *bias, const void *residual, void *out, int B, int M,
+                   int K, int bs_shift, int mode, hipStream_t stream) {
     const int C = K >> 5;
     const int nb = B <= 2 ? 2 : (B <= 4 ? 4 : 8);
-#define FP4_SM(KS, GG, NBB) return launch_small<DT, KS, GG, 2, NBB>(x, W, absmax, bias, out, B, M, K, bs_shift, stream)
+#define FP4_SM(KS, GG, NBB) return launch_small<DT, KS, GG, 2, NBB>(x, W, absmax, bias, residual, out, B, M, K, bs_shift, mode, stream)
 #define FP4_SM_NB(KS, GG)       \
     switch (nb) {               \
         case 2: FP4_SM(KS, GG, 2); \
@@ -687,13 +706,19 @@ void set_small_variant(int v) {
 
 }  // namespace fp4
 
-extern "C" int fp4_hip_gemm_small(const void *x, const uint8_t *packed, const float *absmax, const void *bias, void *out,
-                                  int64_t B, int64_t M, int64_t K, int blocksize, int dtype, void *stream) {
-    using namespace fp4;
+namespace fp4 {
+namespace {
+int gemm_small_entry(const void *x, const uint8_t *packed, const float *absmax, const void *bias, const void *residual, void *out,
+                     int64_t B, int64_t M, int64_t K, int blocksize, int dtype, int mode, void *stream) {
     if (B < 1 || B > 64 || M < 0 || K <= 0) {
         set_error("fp4_hip_gemm_small: B=%lld M=%lld K=%lld (need 1 <= B <= 64)", (long long)B, (long long)M, (long long)K);
         return FP4_ERR_INVALID_ARGUMENT;
     }
+    if ((mode & kModeSiluMulPairs) && (M & 1)) {
+        set_error("fp4_hip_gemm_small_fused: the gate|up epilogue needs an even row count, got M=%lld", (long long)M);
+        return FP4_ERR_INVALID_ARGUMENT;
+    }
+    const int64_t M_out = (mode & kModeSiluMulPairs) ? M / 2 : M;
     if (B > 16) {
         // one launch covers 16 activation rows (the matrix-core tile); more rows are evenly split over several launches,
         // each streaming the weight once - still ahead of dequant + GEMM while launches x 9.45 MB < the 76 MB the
@@ -705,9 +730,10 @@ extern "C" int fp4_hip_gemm_small(const void *x, const uint8_t *packed, const fl
         const int64_t chunks = (B + 15) / 16, per = (B + chunks - 1) / chunks;
         for (int64_t b0 = 0; b0 < B; b0 += per) {
             const int64_t nb = B - b0 < per ? B - b0 : per;
-            const int rc = fp4_hip_gemm_small(static_cast<const uint8_t *>(x) + size_t(b0) * size_t(K) * 2, packed, absmax, bias,
-                                              out ? static_cast<uint8_t *>(out) + size_t(b0) * size_t(M) * 2 : nullptr, nb, M, K,
-                                              blocksize, dtype, stream);
+            const int rc = gemm_small_entry(static_cast<const uint8_t *>(x) + size_t(b0) * size_t(K) * 2, packed, absmax, bias,
+                                            residual ? static_cast<const uint8_t *>(residual) + size_t(b0) * size_t(M_out) * 2 : nullptr,
+                                            out ? static_cast<uint8_t *>(out) + size_t(b0) * size_t(M_out) * 2 : nullptr, nb, M, K,
+                                            blocksize, dtype, mode, stream);
             if (rc != FP4_OK) return rc;
         }
         return FP4_OK;
@@ -728,18 +754,37 @@ extern "C" int fp4_hip_gemm_small(const void *x, const uint8_t *packed, const fl
     const int v_small = g_small_variant.load(std::memory_order_relaxed);
     const bool want_mfma = v_small == 1 || (v_small < 0 && B >= 2);
     if (mfma_ok && (want_mfma || B > 8))
-        rc = dtype == FP4_DTYPE_F16 ? dispatch_mfma<FP4_DTYPE_F16>(x, packed, absmax, bias, out, (int)B, (int)M, (int)K, s)
-                                    : dispatch_mfma<FP4_DTYPE_BF16>(x, packed, absmax, bias, out, (int)B, (int)M, (int)K, s);
+        rc = dtype == FP4_DTYPE_F16 ? dispatch_mfma<FP4_DTYPE_F16>(x, packed, absmax, bias, residual, out, (int)B, (int)M, (int)K, mode, s)
+                                    : dispatch_mfma<FP4_DTYPE_BF16>(x, packed, absmax, bias, residual, out, (int)B, (int)M, (int)K, mode, s);
     if (rc == -1 && ok && B <= 8 && K <= 16384)
-        rc = dtype == FP4_DTYPE_F16 ? dispatch_small<FP4_DTYPE_F16>(x, packed, absmax, bias, out, (int)B, (int)M, (int)K, bs_shift, s)
-                                    : dispatch_small<FP4_DTYPE_BF16>(x, packed, absmax, bias, out, (int)B, (int)M, (int)K, bs_shift, s);
+        rc = dtype == FP4_DTYPE_F16
+                 ? dispatch_small<FP4_DTYPE_F16>(x, packed, absmax, bias, residual, out, (int)B, (int)M, (int)K, bs_shift, mode, s)
+                 : dispatch_small<FP4_DTYPE_BF16>(x, packed, absmax, bias, residual, out, (int)B, (int)M, (int)K, bs_shift, mode, s);
     if (rc == -1 && mfma_ok)
-        rc = dtype == FP4_DTYPE_F16 ? dispatch_mfma<FP4_DTYPE_F16>(x, packed, absmax, bias, out, (int)B, (int)M, (int)K, s)
-                                    : dispatch_mfma<FP4_DTYPE_BF16>(x, packed, absmax, bias, out, (int)B, (int)M, (int)K, s);
+        rc = dtype == FP4_DTYPE_F16 ? dispatch_mfma<FP4_DTYPE_F16>(x, packed, absmax, bias, residual, out, (int)B, (int)M, (int)K, mode, s)
+                                    : dispatch_mfma<FP4_DTYPE_BF16>(x, packed, absmax, bias, residual, out, (int)B, (int)M, (int)K, mode, s);
     if (rc == -1) {
         set_error("fp4_hip_gemm_small: shape B=%lld M=%lld K=%lld blocksize=%d dtype=%d is not covered; use dequant + GEMM",
                   (long long)B, (long long)M, (long long)K, blocksize, dtype);
         return FP4_ERR_UNSUPPORTED;
     }
     return check_launch("fp4_hip_gemm_small");
+}
+}  // namespace
+}  // namespace fp4
+
+extern "C" int fp4_hip_gemm_small(const void *x, const uint8_t *packed, const float *absmax, const void *bias, void *out,
+                                  int64_t B, int64_t M, int64_t K, int blocksize, int dtype, void *stream) {
+    return fp4::gemm_small_entry(x, packed, absmax, bias, nullptr, out, B, M, K, blocksize, dtype, 0, stream);
+}
+
+extern "C" int fp4_hip_gemm_small_fused(const void *x, const uint8_t *packed, const float *absmax, const void *bias,
+                                        const void *residual, void *out, int64_t B, int64_t M, int64_t K, int blocksize, int dtype,
+                                        int epilogue, void *stream) {
+    if (epilogue != FP4_EPILOGUE_NONE && epilogue != FP4_EPILOGUE_SILU_MUL_PAIRS) {
+        fp4::set_error("fp4_hip_gemm_small_fused: unknown epilogue %d", epilogue);
+        return FP4_ERR_INVALID_ARGUMENT;
+    }
+    return fp4::gemm_small_entry(x, packed, absmax, bias, residual, out, B, M, K, blocksize, dtype,
+                                 epilogue == FP4_EPILOGUE_SILU_MUL_PAIRS ? fp4::kModeSiluMulPairs : 0, stream);
 }

@@ -106,5 +106,28 @@ __device__ __forceinline__ void store_silu_mul(uint16_t *out, const uint16_t *bi
     out[pair] = t;
 }
 
+// Small-batch (2..16 activation rows) epilogues: F.linear semantics - the bias is added to the f32 sum BEFORE the one rounding
+// (torch_bnb_fp4/__init__.py:423-436 is dequant + F.linear(A, W, bias)) - then the same optional residual add / gated-MLP
+// product as the GEMV's, each a rounded op of its own.  `sum` is the finished dot product (already times 1/12).
+template <int DT>
+__device__ __forceinline__ void store_small(uint16_t *out, const uint16_t *bias, const uint16_t *residual, int64_t b, int row, int M,
+                                            float sum) {
+    if (bias) sum += to_f32<DT>(bias[row]);
+    uint16_t t = from_f32<DT>(sum);
+    if (residual) t = from_f32<DT>(to_f32<DT>(t) + to_f32<DT>(residual[b * M + row]));
+    out[b * M + row] = t;
+}
+
+template <int DT>
+__device__ __forceinline__ void store_small_silu_mul(uint16_t *out, const uint16_t *bias, const uint16_t *residual, int64_t b, int pair,
+                                                     int M_half, float gate_sum, float up_sum) {
+    if (bias) gate_sum += to_f32<DT>(bias[2 * pair]), up_sum += to_f32<DT>(bias[2 * pair + 1]);
+    const float gf = to_f32<DT>(from_f32<DT>(gate_sum));
+    const uint16_t s = from_f32<DT>(gf / (1.0f + expf(-gf)));
+    uint16_t t = from_f32<DT>(to_f32<DT>(s) * to_f32<DT>(from_f32<DT>(up_sum)));
+    if (residual) t = from_f32<DT>(to_f32<DT>(t) + to_f32<DT>(residual[b * M_half + pair]));
+    out[b * M_half + pair] = t;
+}
+
 }  // namespace
 }  // namespace fp4

@@ -255,6 +255,46 @@ torch::Tensor gemm_small_fp4(torch::Tensor A, torch::Tensor B, torch::Tensor abs
     return out;
 }
 
+// the small-batch product with the fused epilogues (fp4_hip_gemm_small_fused): A [..., K] with 1..64 rows -> [..., m] or [..., m / 2]
+torch::Tensor gemm_small_fp4_fused(torch::Tensor A, torch::Tensor B, torch::Tensor absmax, int blocksize, std::vector<uint32_t> Bshape,
+                                   c10::optional<torch::Tensor> bias, c10::optional<torch::Tensor> residual, int epilogue) {
+    check_gpu_contiguous(A, "A");
+    check_gpu_contiguous(B, "B");
+    check_gpu_contiguous(absmax, "absmax");
+    TORCH_CHECK(Bshape.size() == 2, "Bshape must be [out_features, in_features]");
+    const int64_t m = Bshape[0], k = Bshape[1];
+    TORCH_CHECK(epilogue == FP4_EPILOGUE_NONE || epilogue == FP4_EPILOGUE_SILU_MUL_PAIRS, "gemm_small_fp4_fused: unknown epilogue ", epilogue);
+    const int64_t m_out = epilogue == FP4_EPILOGUE_SILU_MUL_PAIRS ? m / 2 : m;
+    TORCH_CHECK(A.dim() >= 1 && A.size(-1) == k, "gemm_small_fp4_fused: last dim of the activation must be in_features = ", k);
+    const int64_t rows = A.numel() / k;
+    TORCH_CHECK(rows >= 1 && rows <= 64, "gemm_small_fp4_fused covers 1..64 activation rows, got ", rows);
+    TORCH_CHECK(B.dtype() == torch::kUInt8 && B.numel() * 2 >= m * k, "B too small for a ", m, "x", k, " weight");
+    TORCH_CHECK(absmax.scalar_type() == torch::kFloat32 && absmax.numel() * int64_t(blocksize) >= m * k, "absmax too small");
+    const int dt = to_fp4_dtype(A.scalar_type(), "gemm_small_fp4_fused");
+    auto shape = A.sizes().vec();
+    shape.back() = m_out;
+    torch::Tensor out = torch::empty(shape, A.options());
+    const void *bias_ptr = nullptr, *res_ptr = nullptr;
+    torch::Tensor bias_c, res_c;
+    if (bias.has_value()) {
+        TORCH_CHECK(bias->is_cuda() && bias->numel() == m && bias->scalar_type() == A.scalar_type(), "bias must be a [", m,
+                    "] tensor of the activation dtype");
+        bias_c = bias->contiguous();
+        bias_ptr = bias_c.data_ptr();
+    }
+    if (residual.has_value()) {
+        TORCH_CHECK(residual->is_cuda() && residual->numel() == rows * m_out && residual->scalar_type() == A.scalar_type() &&
+                        residual->device() == A.device(),
+                    "residual must hold ", rows * m_out, " elements of the activation dtype on the activation's device");
+        res_c = residual->contiguous();
+        res_ptr = res_c.data_ptr();
+    }
+    c10::DeviceGuard guard(A.device());
+    check_status(fp4_hip_gemm_small_fused(A.data_ptr(), B.data_ptr<uint8_t>(), absmax.data_ptr<float>(), bias_ptr, res_ptr, out.data_ptr(),
+                                          rows, m, k, blocksize, dt, epilogue, current_stream(A)));
+    return out;
+}
+
 // f32 partial sums of a K-split shard: [1, m] float32 (see fp4_hip_gemv_partial)
 torch::Tensor gemv_fp4_partial(torch::Tensor A, torch::Tensor B, torch::Tensor absmax, int blocksize, std::vector<uint32_t> Bshape) {
     check_gpu_contiguous(A, "A");
@@ -380,6 +420,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
           "GEMV with a fused epilogue: (A, B, absmax, blocksize, Bshape, bias|None, residual|None, epilogue) ; epilogue 0 = bias/residual, "
           "1 = silu(gate) * up over interleaved rows");
     m.def("gemm_small_fp4", &gemm_small_fp4, "fused FP4 product for 1..16 activation rows: (A, B, absmax, blocksize, Bshape, bias|None)");
+    m.def("gemm_small_fp4_fused", &gemm_small_fp4_fused,
+          "fused FP4 product for 1..64 rows with an epilogue: (A, B, absmax, blocksize, Bshape, bias|None, residual|None, epilogue)");
     m.def("gemv_fp4_partial", &gemv_fp4_partial, "f32 partial sums of a K-split shard: (A, B, absmax, blocksize, Bshape)");
     m.def("comm_alloc", &comm_alloc, "(world, capacity, device) -> (buffer address, 64-byte IPC handle, memory kind)");
     m.def("comm_open", &comm_open, "(handle, device) -> mapped address of a peer's buffer");

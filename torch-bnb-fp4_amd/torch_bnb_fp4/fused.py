@@ -11,8 +11,9 @@ GEMV's epilogue (``fp4_hip_gemv_fused``):
   ``silu(gate(x)) * up(x)`` in one launch.
 
 Every intermediate is rounded to the activation dtype exactly where the separate torch ops would round it, so the result
-equals the unfused sequence bit for bit (``exp`` is the device library's, as in torch's silu).  Inputs that are not a
-single token, or shapes the fused kernel does not cover, run the unfused sequence through :class:`QuantData`.
+equals the unfused sequence bit for bit (``exp`` is the device library's, as in torch's silu).  2..32 activation rows
+(batched decode) take the same epilogues on the small-batch kernels (``fp4_hip_gemm_small_fused``); larger inputs, or shapes
+the fused kernels do not cover, run the unfused sequence through :class:`QuantData`.
 """
 from __future__ import annotations
 
@@ -62,6 +63,7 @@ class FusedFP4Linear(nn.Module):
         self.in_features = int(quant_data.N)
         self.out_features = int(quant_data.M) // (2 if epilogue == EPILOGUE_SILU_MUL_PAIRS else 1)
         self._fused_ok = True  # cleared the first time the kernel reports the shape as not covered
+        self._small_ok = True
         self.register_buffer("qweight", quant_data.A, persistent=True)
         self.register_buffer("absmax", quant_data.absmax, persistent=True)
 
@@ -126,6 +128,16 @@ class FusedFP4Linear(nn.Module):
                 if "not available" not in str(exc):
                     raise
                 self._fused_ok = False  # shape outside the fused kernel's coverage: unfused sequence from now on
+        rows = x.numel() // K if K else 0
+        if (self._small_ok and 2 <= rows <= 32 and K == self.in_features and x.dtype == qd.o_type and x.dtype in (torch.float16, torch.bfloat16)
+                and ((qd.blocksize == 64 and K % 512 == 0) or (rows <= 8 and K % qd.blocksize == 0 and K % 32 == 0 and K <= 4096))):
+            try:  # batched decode: the same epilogues on the small-batch kernels
+                return ext.gemm_small_fp4_fused(x.contiguous(), qd._B_t, qd.absmax, qd.blocksize, qd._shape_list, qd.bias, residual,
+                                                self.epilogue)
+            except RuntimeError as exc:
+                if "not covered" not in str(exc):
+                    raise
+                self._small_ok = False
         return self._unfused(x, residual)
 
     def extra_repr(self) -> str:
