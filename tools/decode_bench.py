@@ -38,7 +38,7 @@ def fp4_bytes(m, k):
 
 
 def build_token_fn(cfg, dev, dtype, world=1, rank=0, group=None, fuse=False, epilogues=False, batch=1,
-                   reference_dispatch=False, allreduce="dist", lm_head=True, seed=7):
+                   reference_dispatch=False, allreduce="dist", lm_head=True, seed=7, lean_glue=False):
     """Builds the FP4 layers of a `cfg`-shaped decoder and returns (token_fn, h0, meta).
 
     world == 1: QuantData dispatchers (the product's single-GPU path).  world > 1: Column/RowParallelFP4Linear
@@ -53,7 +53,7 @@ def build_token_fn(cfg, dev, dtype, world=1, rank=0, group=None, fuse=False, epi
 
     def fp4_weight(m, k):
         packed = torch.randint(0, 256, (m * k // 2, 1), dtype=torch.uint8, device=dev, generator=gen)
-        absmax = torch.rand(m * k // BS, device=dev, generator=gen) * 0.02 + 0.002
+        absmax = (torch.rand(m * k // BS, device=dev, generator=gen) * 0.02 + 0.002) * (0.25 if lean_glue else 1.0)
         return packed, absmax
 
     code = pkg.ext.code_table("tree").to(dev)
@@ -101,33 +101,47 @@ def build_token_fn(cfg, dev, dtype, world=1, rank=0, group=None, fuse=False, epi
     head = torch.nn.Linear(H, V, bias=False, device=dev, dtype=dtype) if lm_head else None
     h0 = torch.randn(batch, H, device=dev, generator=gen).to(dtype)
     silu = torch.nn.functional.silu
+    # stand-in for attention: keeps k and v live and dependent.  Default: five small launches (two sums, add, scale, add), about what
+    # RoPE + cache append + attention cost a real decoder layer in launches; lean_glue: ONE elementwise launch, and no rescale of h
+    # (the weights' scales keep magnitudes bounded instead) - the floor of everything that is not an FP4 Linear.
+    if lean_glue:
+        def attn(q, k, v):
+            return torch.addcmul(q, k[..., :1], v[..., :1], value=0.0)
+        rescale = 1.0
+    else:
+        def attn(q, k, v):
+            return q + 0.0 * (k.sum() + v.sum())
+        rescale = 0.5
 
     def token(h):
         for ly in layers:
             if "tp_qkv" in ly:
                 q, k, v = ly["tp_qkv"](h).split(ly["tp_qkv"].split_sizes, dim=-1)
-                a = q + 0.0 * (k.sum() + v.sum())
+                a = attn(q, k, v)
                 h = ly["o"](a.contiguous(), residual=h)
-                h = ly["down"](ly["tp_gate_up"](h), residual=h) * 0.5
+                h = ly["down"](ly["tp_gate_up"](h), residual=h)
+                h = h * rescale if rescale != 1.0 else h
                 continue
             if "gate_up" in ly and epilogues and world == 1:
                 q, k, v = ly["qkv"](h).split([H, KV, KV], dim=-1)
-                a = q + 0.0 * (k.sum() + v.sum())
-                h = ly["o"](a.contiguous(), residual=h)            # h + o(a), one launch
-                h = ly["down"](ly["gate_up"](h), residual=h) * 0.5  # silu(g)*u in the gate|up epilogue, + h in down's
+                a = attn(q, k, v)
+                h = ly["o"](a.contiguous(), residual=h)       # h + o(a), one launch
+                h = ly["down"](ly["gate_up"](h), residual=h)  # silu(g)*u in the gate|up epilogue, + h in down's
+                h = h * rescale if rescale != 1.0 else h
                 continue
             if "qkv" in ly:
                 q, k, v = ly["qkv"](h).split([H, KV, KV], dim=-1)
-                a = q + 0.0 * (k.sum() + v.sum())
+                a = attn(q, k, v)
                 h = h + ly["o"](a.contiguous())
                 g, u = ly["gate_up"](h).split([I, I], dim=-1)
-                h = (h + ly["down"](silu(g) * u)) * 0.5
+                h = h + ly["down"](silu(g) * u)
+                h = h * rescale if rescale != 1.0 else h
                 continue
             q, k, v = ly["q"](h), ly["k"](h), ly["v"](h)
-            a = q + 0.0 * (k.sum() + v.sum())  # stand-in for attention: keeps k, v live and dependent
+            a = attn(q, k, v)
             h = h + ly["o"](a)
             h = h + ly["down"](silu(ly["gate"](h)) * ly["up"](h))
-            h = h * 0.5  # keep magnitudes bounded over many layers of random weights
+            h = h * rescale if rescale != 1.0 else h  # keep magnitudes bounded over many layers of random weights
         return head(h) if head is not None else h
 
     per_token_fp4 = L * (2 * fp4_bytes(H, H) + 2 * fp4_bytes(KV, H) + 2 * fp4_bytes(I, H) + fp4_bytes(H, I)) // world
@@ -194,6 +208,8 @@ def main():
     ap.add_argument("--allreduce", default="dist", choices=("dist", "oneshot"),
                     help="world > 1: torch.distributed all-reduce (RCCL) or the one-shot peer-slot kernel")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--lean-glue", action="store_true",
+                    help="attention stand-in as ONE elementwise launch and no rescale: what is left besides the FP4 Linears is minimal")
     args = ap.parse_args()
     cfg = dict(MODELS[args.model])
     if args.layers:
@@ -211,7 +227,7 @@ def main():
             dist.init_process_group(backend)
     dtype = getattr(torch, args.dtype)
     token, h0, meta = build_token_fn(cfg, dev, dtype, world, rank, fuse=args.fuse, epilogues=args.epilogues, batch=args.batch,
-                                     reference_dispatch=args.reference_dispatch, allreduce=args.allreduce)
+                                     reference_dispatch=args.reference_dispatch, allreduce=args.allreduce, lean_glue=args.lean_glue)
 
     def barrier():
         torch.cuda.synchronize()
@@ -228,6 +244,7 @@ def main():
         print(json.dumps({
             "model": args.model, "layers": meta["layers"], "n_gpus": world, "dtype": args.dtype,
             "fp4_linear_calls_per_token": meta["fp4_linear_calls_per_token"], "epilogues_fused": bool(args.epilogues and world == 1),
+            "glue": "lean (1 elementwise launch per layer)" if args.lean_glue else "default (6 small launches per layer)",
             "fp4_bytes_per_token_per_gpu": per_token_fp4, "eager_ms_per_step": round(t["eager_s"] * 1e3, 3),
             "graph_ms_per_step": None if t["graph_s"] is None else round(t["graph_s"] * 1e3, 3),
             "batch": args.batch, "batch_path": "reference dispatch (dequant + GEMM)" if args.reference_dispatch and args.batch > 1 else "fused",
