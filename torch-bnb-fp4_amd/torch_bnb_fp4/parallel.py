@@ -187,7 +187,8 @@ class RowParallelFP4Linear(nn.Module):
                 qd.set_compute_type(xs)
             w32 = ext.dequantize_fp4_codebook(qd.A, qd.absmax, qd.code, qd.M, qd.N, qd.blocksize, qd.numel, ScalarType.float32.value)
             part = torch.nn.functional.linear(xs.float(), w32)
-        if self.world > 1 and self.allreduce == "oneshot" and part.is_cuda:
+        if self.world > 1 and self.allreduce == "oneshot" and part.is_cuda and part.numel() <= 65536:
+            # (latency-bound sizes only: decode and small batches; a prefill-sized partial goes through torch.distributed below)
             # one launch: publish into every peer's slots, gather, sum in rank order, round once, bias / residual on top
             comm = oneshot_comm(self.group, part.numel())
             bias = None if self.bias is None else self.bias.to(x.dtype)
