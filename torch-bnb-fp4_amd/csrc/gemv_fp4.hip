@@ -231,13 +231,19 @@ __global__ __launch_bounds__(WAVES * 64, (G >= 4 ? 4 : 1)) void gemv16_regx_kern
 #endif
         }
     };
+    // Weights and scales come through buffer descriptors: a wave-uniform base + one 32-bit offset per lane, instead of a 64-bit
+    // multiply-add and two 64-bit shifts per load on the VALU - this kernel is vector-issue-bound in steady state
+    // (profiles/r02_gemv_steady_state_sq_counters.txt).  The dispatcher only comes here while M * K < 2^32.
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(W), 0, int((uint32_t(M) * uint32_t(C)) << 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_a =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(absmax), 0, int(((uint32_t(M) * uint32_t(C)) >> (bs_shift - 5)) << 2), 0x00020000);
     auto load_w = [&](int it, int g) {
-        const int64_t chunk = int64_t(rclamp[it]) * C + cidx[g];
-        wq[it][g] = __builtin_nontemporal_load(Wv + chunk);
+        const uint32_t chunk = uint32_t(rclamp[it]) * uint32_t(C) + uint32_t(cidx[g]);
+        wq[it][g] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, int(chunk << 4), 0, 2));  // aux 2 = nt
 #ifdef FP4_ABL_NOABSMAX
         const float a = 0.5f;
 #else
-        const float a = absmax[(chunk << 5) >> bs_shift];
+        const float a = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_a, int((chunk >> (bs_shift - 5)) << 2), 0, 0));
 #endif
         am[it][g] = live[g] ? a : 0.0f;
     };
@@ -280,22 +286,24 @@ __global__ __launch_bounds__(WAVES * 64, (G >= 4 ? 4 : 1)) void gemv16_regx_kern
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) pacc[it] = 0.0f;
     auto consume = [&](int it, int g) {
-        float s[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        // two accumulation chains per 32-weight chunk (eight dependent v_dot2 each): with several waves per SIMD the chain latency
+        // is covered, and one add per chunk replaces three
+        float s[2] = {0.0f, 0.0f};
 #ifdef FP4_ABL_NOCOMPUTE
 #pragma unroll
-        for (int q = 0; q < 4; ++q) s[q] = __builtin_bit_cast(float, (wq[it][g][q] ^ xd[g][q].x) & 0x3fffffffu);
+        for (int q = 0; q < 4; ++q) s[q & 1] = __builtin_bit_cast(float, (wq[it][g][q] ^ xd[g][q].x) & 0x3fffffffu);
 #else
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             uint32_t P[4];
             decode8<DT>(wq[it][g][q], P);
-            s[q] = dot2<DT>(P[0], xd[g][q].x, s[q]);
-            s[q] = dot2<DT>(P[1], xd[g][q].y, s[q]);
-            s[q] = dot2<DT>(P[2], xd[g][q].z, s[q]);
-            s[q] = dot2<DT>(P[3], xd[g][q].w, s[q]);
+            s[q & 1] = dot2<DT>(P[0], xd[g][q].x, s[q & 1]);
+            s[q & 1] = dot2<DT>(P[1], xd[g][q].y, s[q & 1]);
+            s[q & 1] = dot2<DT>(P[2], xd[g][q].z, s[q & 1]);
+            s[q & 1] = dot2<DT>(P[3], xd[g][q].w, s[q & 1]);
         }
 #endif
-        pacc[it] = __builtin_fmaf((s[0] + s[1]) + (s[2] + s[3]), am[it][g], pacc[it]);
+        pacc[it] = __builtin_fmaf(s[0] + s[1], am[it][g], pacc[it]);
     };
     if constexpr (GMAJOR) {
         // group by group, fenced: without the fence hipcc hoists every group's x permutes above the first dot2, i.e.
@@ -705,6 +713,7 @@ int launch_regx(const GemvArgs &a) {
 template <int DT>
 int dispatch_regx(int iters, int ks_override, const GemvArgs &a) {
     const int C = a.K >> 5;
+    if (int64_t(a.M) * a.K >= (int64_t(1) << 32)) return -1;  // 32-bit buffer offsets; the LDS geometry addresses with 64 bits
     if (ks_override == 8 && C > 64 && C <= 128) {  // sweep hook: 8 waves per workgroup (two row-pair groups)
         if (iters == 1) return launch_regx<DT, 4, 1, 1, 8>(a);
         if (iters == 2) return launch_regx<DT, 4, 1, 2, 8>(a);
