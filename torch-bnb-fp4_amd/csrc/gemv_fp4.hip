@@ -193,7 +193,6 @@ __global__ __launch_bounds__(WAVES * 64, (G >= 4 ? 4 : 1)) void gemv16_regx_kern
     const int half = lane >> 5, l32 = lane & 31;
     const int C = K >> 5;
     const int row_base = blockIdx.x * kRowsPerBlock;
-    const u32x4 *Wv = reinterpret_cast<const u32x4 *>(W);
 
     // Everything below is branch-free (see issue_trip): dead lanes / rows are clamped and get a zero scale.
     int cidx[G];
