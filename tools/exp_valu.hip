@@ -92,6 +92,14 @@ __global__ __launch_bounds__(256) void k(uint32_t *out, uint32_t seed) {
             if constexpr (OP == 37) asm volatile("v_max_f32 %0, |%0|, |%1|" : "+v"(f[i]) : "v"(b));
             if constexpr (OP == 38) asm volatile("v_bfi_b32 %0, %1, %0, %2" : "+v"(a[i]) : "v"(b), "v"(c));
             if constexpr (OP == 39) asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+            // round 2: gfx950 low-precision conversions and SDWA forms, candidates for a cheaper FP4 decode
+            if constexpr (OP == 40) asm volatile("v_cvt_scalef32_pk_bf16_fp8 %0, %1, %2" : "=v"(a[i]) : "v"(a[(i + 1) & 15]), "v"(f[0]));
+            if constexpr (OP == 41) asm volatile("v_cvt_scalef32_pk_f16_fp8 %0, %1, %2" : "=v"(a[i]) : "v"(a[(i + 1) & 15]), "v"(f[0]));
+            if constexpr (OP == 42) asm volatile("v_cvt_scalef32_pk_bf16_fp4 %0, %1, %2" : "=v"(a[i]) : "v"(a[(i + 1) & 15]), "v"(f[0]));
+            if constexpr (OP == 43) asm volatile("v_cvt_scalef32_pk_f32_fp4 %0, %1, %2" : "=v"(*reinterpret_cast<f32x2 *>(&f[i & 14])) : "v"(a[i]), "v"(f[0]));
+            if constexpr (OP == 44) asm volatile("v_lshlrev_b32_sdwa %0, %1, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "+v"(a[i]) : "v"(b));
+            if constexpr (OP == 45) asm volatile("v_mov_b32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2" : "+v"(a[i]) : "v"(b));
+            if constexpr (OP == 46) asm volatile("v_pk_mul_f32 %0, %1, %1" : "=v"(*reinterpret_cast<f32x2 *>(&f[i & 14])) : "v"(*reinterpret_cast<f32x2 *>(&f[(i + 2) & 14])));
             if constexpr (OP == 11) {  // v_cvt_f32_f16 (SDWA-free) + fma
                 f[i] = __builtin_fmaf(float(__builtin_bit_cast(f16x2, a[i]).x), f[i], 1.0f);
             }
@@ -147,6 +155,19 @@ int main() {
         run<37>("v_max_f32 |a|,|b|", 1, out);
         run<26>("v_max3_f32", 1, out);
         run<27>("v_pk_add_f32", 1, out);
+        return 0;
+    }
+    if (getenv("EXP_VALU_CVT")) {
+        run<1>("v_perm_b32", 1, out);
+        run<2>("v_dot2c_f32_bf16", 1, out);
+        run<14>("v_and_b32", 1, out);
+        run<40>("v_cvt_scalef32_pk_bf16_fp8", 1, out);
+        run<41>("v_cvt_scalef32_pk_f16_fp8", 1, out);
+        run<42>("v_cvt_scalef32_pk_bf16_fp4", 1, out);
+        run<43>("v_cvt_scalef32_pk_f32_fp4", 1, out);
+        run<44>("v_lshlrev_b32_sdwa (BYTE_1)", 1, out);
+        run<45>("v_mov_b32_sdwa (dst BYTE_1 preserve)", 1, out);
+        run<46>("v_pk_mul_f32", 1, out);
         return 0;
     }
     run<0>("v_fma_f32", 1, out);

@@ -10,9 +10,9 @@ namespace {
 // ---- byte tables for v_perm_b32: magnitude index 0..7 -> 12*|code| --------------------------
 // fp16 patterns 0x0000 0x2C00 0x4800 0x4A00 0x4400 0x4600 0x4000 0x4200 (low byte always 0)
 constexpr uint32_t kF16HiLo = 0x4A482C00u, kF16HiHi = 0x42404644u;
-// bf16 patterns 0x0000 0x3D80 0x4100 0x4140 0x4080 0x40C0 0x4000 0x4040
-constexpr uint32_t kBf16HiLo = 0x41413D00u, kBf16HiHi = 0x40404040u;
-constexpr uint32_t kBf16LoLo = 0x40008000u, kBf16LoHi = 0x4000C080u;
+// OCP E4M3 patterns of the same eight values (exact): 0x00 0x18 0x50 0x54 0x48 0x4C 0x40 0x44 - the bf16 path widens them with
+// v_cvt_scalef32_pk_bf16_fp8 (bf16 itself would need two byte planes: 0x0000 0x3D80 0x4100 0x4140 0x4080 0x40C0 0x4000 0x4040)
+constexpr uint32_t kE4M3Lo = 0x54501800u, kE4M3Hi = 0x44404C48u;
 
 __device__ __forceinline__ uint32_t perm(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
 
@@ -32,14 +32,17 @@ __device__ __forceinline__ void decode8(uint32_t q, uint32_t (&P)[4]) {
         P[2] = perm(0u, mlo, 0x010C000Cu);
         P[3] = perm(0u, mlo, 0x030C020Cu);
     } else {
-        const uint32_t hH = perm(kBf16HiHi, kBf16HiLo, hi_sel) | hi_sgn;
-        const uint32_t hL = perm(kBf16LoHi, kBf16LoLo, hi_sel);
-        const uint32_t lH = perm(kBf16HiHi, kBf16HiLo, lo_sel) | lo_sgn;
-        const uint32_t lL = perm(kBf16LoHi, kBf16LoLo, lo_sel);
-        P[0] = perm(hH, hL, 0x05010400u);
-        P[1] = perm(hH, hL, 0x07030602u);
-        P[2] = perm(lH, lL, 0x05010400u);
-        P[3] = perm(lH, lL, 0x07030602u);
+        // bf16 has no one-byte pattern for 12*|code| (the x1.5 values need mantissa bit 6), so a two-plane v_perm decode costs 8
+        // v_perm per 8 weights.  gfx950's packed FP8 -> bf16 conversion does the widening instead: 12*|code| is exact in OCP E4M3,
+        // one v_perm per nibble plane looks the E4M3 byte up, the sign is bit 7 there as well, and v_cvt_scalef32_pk_bf16_fp8
+        // (scale 1.0, exact) turns bytes (0,1) / (2,3) of a plane into the same (e0,e2) (e4,e6) (e1,e3) (e5,e7) pairs:
+        // 2 v_perm + 4 conversions (same issue rate as v_perm, profiles/r02_valu_cvt_rates.txt) instead of 8 v_perm.
+        const uint32_t mhi = perm(kE4M3Hi, kE4M3Lo, hi_sel) | hi_sgn;
+        const uint32_t mlo = perm(kE4M3Hi, kE4M3Lo, lo_sel) | lo_sgn;
+        P[0] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(mhi, 1.0f, false));
+        P[1] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(mhi, 1.0f, true));
+        P[2] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(mlo, 1.0f, false));
+        P[3] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(mlo, 1.0f, true));
     }
 }
 
