@@ -427,11 +427,16 @@ __global__ __launch_bounds__(512) void gemm16_mfma_persist_kernel(const uint16_t
     constexpr int kXUnits = XS ? XS * NBW / 8 : 1;
     __shared__ __attribute__((aligned(16))) uint8_t s_w[8 * 16 * kStageStride];
     __shared__ __attribute__((aligned(16))) uint8_t s_x[XS ? 8 * XS * kXStride : 16];
-    __shared__ __attribute__((aligned(16))) float s_part[8][256];
+    // Above 4 rows one workgroup owns the CU anyway (LDS), so the cross-wave partials are double-buffered there: tile t writes buffer
+    // t & 1, its reducers read it behind the tile's one barrier, tile t + 2 overwrites it only behind tile t + 1's barrier - one
+    // workgroup barrier per tile instead of two.  Up to 4 rows a second buffer would cost the second workgroup per CU.
+    constexpr int NBUF = XS == 4 ? 1 : 2;
+    __shared__ __attribute__((aligned(16))) float s_part[NBUF][8][256];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, kb = lane >> 4;
     const int nblk = K >> 6;
     const int b0 = wave * NBW;
+    int par = 0;
     const u32x4 *x4 = reinterpret_cast<const u32x4 *>(x);
     uint8_t *img = s_w + wave * 16 * kStageStride;
     uint8_t *ximg = s_x + wave * XS * kXStride;
@@ -537,12 +542,12 @@ __global__ __launch_bounds__(512) void gemm16_mfma_persist_kernel(const uint16_t
             acc.z = __builtin_fmaf(t16.z, am[2][j], acc.z);
             acc.w = __builtin_fmaf(t16.w, am[3][j], acc.w);
         }
-        *reinterpret_cast<f32x4 *>(&s_part[wave][lane * 4]) = acc;
+        *reinterpret_cast<f32x4 *>(&s_part[par][wave][lane * 4]) = acc;
         __syncthreads();
         if (tid < 256) {
             float t = 0.0f;
 #pragma unroll
-            for (int w = 0; w < 8; ++w) t += s_part[w][tid];
+            for (int w = 0; w < 8; ++w) t += s_part[par][w][tid];
             const int l = tid >> 2, reg = tid & 3;  // D layout: col = l & 15 (activation row), row = (l >> 4) * 4 + reg
             const int n = l & 15, row = tile * 16 + (l >> 4) * 4 + reg;
             if (row < M && n < B) {
@@ -550,7 +555,7 @@ __global__ __launch_bounds__(512) void gemm16_mfma_persist_kernel(const uint16_t
                     if (!(reg & 1)) {
                         float u = 0.0f;
 #pragma unroll
-                        for (int w = 0; w < 8; ++w) u += s_part[w][tid + 1];
+                        for (int w = 0; w < 8; ++w) u += s_part[par][w][tid + 1];
                         store_small_silu_mul<DT>(out, bias, residual, n, row >> 1, M >> 1, t * (1.0f / 12.0f), u * (1.0f / 12.0f));
                     }
                 } else {
@@ -558,7 +563,10 @@ __global__ __launch_bounds__(512) void gemm16_mfma_persist_kernel(const uint16_t
                 }
             }
         }
-        __syncthreads();  // s_part is rewritten by the next tile
+        if constexpr (NBUF == 1)
+            __syncthreads();  // s_part is rewritten by the next tile
+        else
+            par ^= 1;
         if (!has_next) break;
         tile = next;
     }
