@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
 """Per-kernel timing of a rocprofv3 kernel trace of `bench.py`, from the dispatches' start / end TIMESTAMPS.
 
-rocprofv3's --stats table reports a kernel's average DURATION (end - start of each dispatch).  For short kernels launched
-back to back that is not the time a launch costs: consecutive dispatches overlap (the next kernel's first waves start
-while the previous kernel's last waves drain) or are separated by a gap, so duration != launch-to-launch interval.  What
-bench.py measures with HIP events is the interval.  This tool reports both, per kernel and grid, and rebuilds the timed
-step from them:   sum over kernels of (launches per step x mean interval)  must reproduce the bench's ms_per_step, and
-the sum of durations may exceed it exactly by the measured overlap.
+rocprofv3's --stats table reports a kernel's average DURATION (end - start of each dispatch), per kernel NAME.  For the
+short kernels of bench.py that is not directly the time a launch costs: what bench.py measures with HIP events is the
+launch-to-launch interval, one kernel name serves several problem sizes (per-name averages mix them), and the trace
+itself changes the timing (dispatches are serialised, ~1 us is added to each).  This tool reports duration, interval and
+gap per kernel AND grid from the dispatch timestamps and rebuilds the timed step from them, against the bench line of
+the SAME profiled run:   sum of durations per step  <=  that run's ms_per_step.
 
 usage: tools/trace_summary.py <kernel_trace.csv> <out.json> [--bench-json bench_line.json]
 """
@@ -77,8 +77,9 @@ def main():
                 "ms_per_step_from_durations": round(step_from_durations, 4),
                 "ms_per_step_bench_hip_events": bench["ms_per_step"],
                 "bench_dequant_us": bench["dequant_us_per_matrix"], "bench_gemv_us": bench["gemv_us_per_layer"],
-                "note": "the profiled run's own bench line (profiling slows the clock a little: never compare with an un-profiled line); "
-                        "intervals reproduce the HIP-event figures, durations double-count the overlap of consecutive dispatches",
+                "note": "compare only within this profiled run: the kernel trace serialises dispatches (median gap between one dispatch's end "
+                        "and the next one's start: 0) and adds ~1 us to kernels this short, so the sum of durations stays below the run's own "
+                        "ms_per_step, and both are above the un-profiled figures of bench.py",
             }
     json.dump(out, open(out_path, "w"), indent=1)
     print(json.dumps(out.get("step_reconstruction", {}), indent=1))
