@@ -161,7 +161,13 @@ def test_fused_layers_match_the_unfused_modules_and_capture_into_a_graph():
     graph.replay()
     torch.cuda.synchronize()
     assert torch.equal(out, dn(gu(h * 0.5), residual=h * 0.5))
-    # batch of 2: unfused fallback, same meaning
+    # the packaged form of the same thing
+    step = pkg.GraphedStep(lambda t: dn(gu(t), residual=t), h)
+    for scale in (1.0, 0.75, -0.5):
+        assert torch.equal(step(h * scale), dn(gu(h * scale), residual=h * scale))
+    with pytest.raises(ValueError):
+        step(torch.cat([h, h]))
+    # batch of 2: the small-batch kernels with the same epilogues
     h2 = torch.cat([h, h * 0.25])
     got2 = dn(gu(h2), residual=h2)
     want2 = h2 + fp[2](torch.nn.functional.silu(fp[0](h2)) * fp[1](h2))

@@ -24,6 +24,7 @@ from .functional import (
 )
 from .comm import OneShotAllReduce
 from .fused import FusedFP4Linear
+from .graphs import GraphedStep
 from .linear import TorchFP4Linear
 from .nn import Linear4bit, LinearFP4, Params4bit, QuantState
 from .quant_data import QuantData
@@ -66,5 +67,6 @@ __all__ = [
     "FusedGatedMLP",
     "FusedFP4Linear",
     "OneShotAllReduce",
+    "GraphedStep",
 ]
 __version__ = "0.1.0"
