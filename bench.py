@@ -595,8 +595,8 @@ def main():
                 "traffic": None,
                 "bytes_per_launch": dq_b,
                 "avg_launch_us": round(dq_us, 3),
-                "method": "HIP events around each graph replay of R back-to-back launches on the launch stream; "
-                          "includes one kernel boundary per launch (rocprofv3 kernel durations: profiles/)",
+                "method": "HIP events around each graph replay of R back-to-back launches on the launch stream; includes one kernel "
+                          "boundary per launch; rocprofv3 trace of this command: profiles/r02_bench_kernel_trace_summary.json",
             },
             "roofline_gemv": {
                 "bound": "hbm", "kernel": "gemv16_regx_kernel<bf16> (fp4_hip_gemv)", "achieved": round(gv_gbps_gpu, 1),
@@ -616,6 +616,12 @@ def main():
         line["dequant_step_spread"] = spread(dq_ms, R)
         line["gemv_step_spread"] = spread(gv_ms, R * GR)
         line.update(extra)
+        # the same kernels away from the launch boundary (one launch over a stack of R weights): what the kernel itself streams at
+        if "dequant_stack_of_R_one_launch_gbps" in extra:
+            line["roofline"]["steady_state_gbps"] = extra["dequant_stack_of_R_one_launch_gbps"]
+            line["roofline"]["steady_state_frac"] = round(extra["dequant_stack_of_R_one_launch_gbps"] / HBM_PEAK_GBPS, 4)
+            line["roofline_gemv"]["steady_state_gbps"] = extra["gemv_stack_of_R_one_launch_gbps"]
+            line["roofline_gemv"]["steady_state_frac"] = round(extra["gemv_stack_of_R_one_launch_gbps"] / HBM_PEAK_GBPS, 4)
         if "dequant_plus_hipblaslt_gemv_us" in extra:
             line["fused_gemv_speedup_vs_dequant_hipblaslt"] = round(extra["dequant_plus_hipblaslt_gemv_us"] / gv_us, 2)
         if world == 1 and not args.no_cpu:
