@@ -176,7 +176,7 @@ def test_fused_layers_match_the_unfused_modules_and_capture_into_a_graph():
 
 @pytest.mark.parametrize("dtype", DT16)
 @pytest.mark.parametrize("B", [1, 2, 4, 8, 11, 16, 24])
-@pytest.mark.parametrize("M,K", [(4096, 4096), (6144, 4096), (258, 2048), (130, 14336), (66, 1024), (36, 8192)])
+@pytest.mark.parametrize("M,K", [(4096, 4096), (6144, 4096), (258, 2048), (130, 14336), (66, 1024), (36, 8192), (66, 768), (34, 1280)])
 def test_small_batch_epilogues(dtype, B, M, K):
     """fp4_hip_gemm_small_fused (batched decode): the residual epilogue is BIT-EXACT against the numpy oracle applied to the plain
     small-batch product (same kernel, same sum); the gated epilogue within 1 ulp of torch's silu(g) * u on that product's
