@@ -161,6 +161,18 @@ def test_fused_layers_match_the_unfused_modules_and_capture_into_a_graph():
     graph.replay()
     torch.cuda.synchronize()
     assert torch.equal(out, dn(gu(h * 0.5), residual=h * 0.5))
+    # state_dict carries the packed weight, the scales and the (compute-dtype) bias; loading new scales reaches the kernel
+    sd = {k: v.clone() for k, v in dn.state_dict().items()}  # (state_dict() hands out the live buffers; load copies in place)
+    assert set(sd) == {"qweight", "absmax", "bias"} and sd["bias"].dtype == torch.bfloat16
+    sd2 = {k: v.clone() for k, v in sd.items()}
+    sd2["absmax"] = sd2["absmax"] * 2.0
+    mid = gu(h)
+    before = dn(mid)
+    dn.load_state_dict(sd2)
+    after = dn(mid)
+    assert (after.float() - (2.0 * (before.float() - sd["bias"].float()) + sd["bias"].float())).abs().max().item() <= 0.03 * after.float().abs().max().item() + 0.02
+    dn.load_state_dict(sd)
+    assert torch.equal(dn(mid), before)
     # the packaged form of the same thing
     step = pkg.GraphedStep(lambda t: dn(gu(t), residual=t), h)
     for scale in (1.0, 0.75, -0.5):

@@ -66,6 +66,7 @@ class FusedFP4Linear(nn.Module):
         self._small_ok = True
         self.register_buffer("qweight", quant_data.A, persistent=True)
         self.register_buffer("absmax", quant_data.absmax, persistent=True)
+        self.register_buffer("bias", None if quant_data.bias is None else quant_data.bias.detach(), persistent=True)
 
     # -- constructors ------------------------------------------------------------------------------------------------
     @classmethod
@@ -102,9 +103,14 @@ class FusedFP4Linear(nn.Module):
         super()._apply(fn, recurse)
         qd = self.quant_data
         if self.qweight.device != qd.A.device:  # device move: the dispatcher follows the buffers
-            bias = None if qd.bias is None else qd.bias.to(self.qweight.device)
-            qd.rebind(self.qweight, self.absmax, qd.code.to(self.qweight.device), bias)
+            qd.rebind(self.qweight, self.absmax, qd.code.to(self.qweight.device), self.bias)
+            if qd.bias is not None:
+                self._buffers["bias"] = qd.bias
         return self
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        super()._load_from_state_dict(*args, **kwargs)
+        self.quant_data.rebind(self.qweight, self.absmax, self.quant_data.code, self.bias)
 
     # -- forward -----------------------------------------------------------------------------------------------------
     def _unfused(self, x: torch.Tensor, residual: Optional[torch.Tensor]) -> torch.Tensor:
@@ -118,6 +124,8 @@ class FusedFP4Linear(nn.Module):
         K = x.shape[-1]
         if not qd.compute_dtype_set and x.numel():
             qd.set_compute_type(x)
+            if qd.bias is not None:
+                self._buffers["bias"] = qd.bias  # the buffer follows the cast to the compute dtype
         if (self._fused_ok and x.numel() == K and K == self.in_features and x.ndim in (2, 3) and K % qd.blocksize == 0
                 and x.dtype == qd.o_type):
             if not x.is_contiguous():
