@@ -514,9 +514,15 @@ def main():
             big_p, big_a = torch.cat(packed), torch.cat(absmax)
             big_o = torch.empty(R * n, dtype=torch.bfloat16, device=dev)
             big_y = torch.empty(R * M, dtype=torch.bfloat16, device=dev)
-            us = time_replays(capture(lambda: [lib.dequant(big_p, big_a, big_o, R * n) for _ in range(4)]), 5, 4)[0]
+            # Each figure is taken after ~25 ms of the same kernel: the first replays after a change of kernel run at clocks
+            # that have not settled and read 5-15 % low (tools/exp_stack_measure.py, profiles/r02_stack_measurement_method.txt).
+            rp = capture(lambda: [lib.dequant(big_p, big_a, big_o, R * n) for _ in range(4)])
+            time_replays(rp, 15, 4)
+            us = time_replays(rp, 9, 4)[0]
             extra["dequant_stack_of_R_one_launch_gbps"] = round(R * dequant_bytes(M, K, BLOCKSIZE, 2) / us / 1e3, 1)
-            us = time_replays(capture(lambda: [lib.gemv(x, big_p, big_a, big_y, R * M, K) for _ in range(12)]), 5, 12)[0]
+            rp = capture(lambda: [lib.gemv(x, big_p, big_a, big_y, R * M, K) for _ in range(12)])
+            time_replays(rp, 20, 12)
+            us = time_replays(rp, 9, 12)[0]
             extra["gemv_stack_of_R_one_launch_gbps"] = round(gemv_bytes(R * M, K, BLOCKSIZE, 2) / us / 1e3, 1)
             del big_p, big_a, big_o, big_y
             # end-to-end through the Python op surface (host overhead visible, like the reference's README table)
