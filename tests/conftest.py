@@ -30,7 +30,7 @@ def _restore_kernel_variants(request):
     if request.node.get_closest_marker("gpu") is not None:
         import hipabi
 
-        for kernel in ("dequant", "gemv", "gemm_small"):
+        for kernel in ("dequant", "gemv", "gemm_small", "gemm_wide"):
             hipabi.set_variant(kernel, -1)
         hipabi.set_variant("quantize", 0)
 

@@ -303,15 +303,19 @@ def test_small_batch_persistent_kernel(dtype, B, M):
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("B", [17, 24, 32, 33, 64])
 @pytest.mark.parametrize("M,K", [(4096, 4096), (300, 8192), (66, 2048)])
-def test_small_batch_beyond_16_rows_is_chunked(dtype, B, M, K):
-    """17..64 rows: evenly split over ceil(B/16) launches; each row of the result equals what a single-chunk call on that row's
-    chunk gives (bit for bit) and meets the GEMV bar against the float64 product.  65 rows are refused."""
+def test_small_batch_beyond_16_rows_chunked_path(dtype, B, M, K):
+    """17..64 rows with the one-pass kernel switched off: evenly split over ceil(B/16) launches; each row of the result equals
+    what a single-chunk call on that row's chunk gives (bit for bit) and meets the GEMV bar against the float64 product."""
     packed, am, _ = make_case(M, K, seed=B + M)
     rng = np.random.default_rng(B * 3 + K)
     x = rng.standard_normal((B, K)).astype(np.float32)
     x_t = torch_values(x, dtype)
     P, A = to_dev(packed), to_dev(am)
-    y = hipabi.gemm_small(x_t, P, A, M, K, 64)
+    hipabi.set_variant("gemm_wide", 0)
+    try:
+        y = hipabi.gemm_small(x_t, P, A, M, K, 64)
+    finally:
+        hipabi.set_variant("gemm_wide", -1)
     chunks = -(-B // 16)
     per = -(-B // chunks)
     parts = [hipabi.gemm_small(x_t[b0:b0 + per].contiguous(), P, A, M, K, 64) for b0 in range(0, B, per)]
@@ -322,7 +326,73 @@ def test_small_batch_beyond_16_rows_is_chunked(dtype, B, M, K):
         exact = c_oracle.gemv_f64(xv, packed, am, M, K, 64)
         err = np.abs(y[b].float().cpu().numpy() - exact)
         assert (err <= HALF_ULP[dtype] * 1.01 * np.abs(exact) + 1e-5 * (wabs @ np.abs(xv)) + 1e-30).all(), (b, err.max())
-    too_many = torch.zeros(65, K, dtype=dtype, device=dev())
+
+
+WIDE_SHAPES = [(4096, 4096), (1024, 4096), (300, 8192), (66, 2048), (33, 512), (130, 14336), (257, 1024)]
+_WIDE_CASES = {}
+
+
+def wide_case(M, K):
+    """One weight per shape, with its exact f32 values as float64 (shared by the parametrised cases below)."""
+    if (M, K) not in _WIDE_CASES:
+        packed, am, _ = make_case(M, K, seed=31 + M)
+        _WIDE_CASES[(M, K)] = (packed, am, o.dequantize_f32(packed, am, 64, M * K).reshape(M, K).astype(np.float64))
+    return _WIDE_CASES[(M, K)]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6, 7, 9, 11])  # (row tiles per wave, row groups per workgroup) = (1,1) (2,1) (2,2) (2,4) (1,2); 6, 7: the all-DMA ring kernel with 2 / 1 row tiles; +8: streaming instead of resident weights
+@pytest.mark.parametrize("B", [17, 24, 32, 33, 40, 48, 49, 64])
+@pytest.mark.parametrize("M,K", WIDE_SHAPES)
+def test_wide_batch_one_pass_kernel(dtype, cfg, B, M, K):
+    """17..64 activation rows in ONE pass over the weight (gemm16_wide_kernel: x through LDS by LDS-DMA, 2..4 column tiles per
+    decoded weight fragment), every workgroup shape forced at every size: ragged M (33, 66, 130, 257, 300: clamped rows, last
+    workgroup partly empty), B not a multiple of 16 (clamped columns), 1..28 steps per K slice.  Every row of the result meets
+    the GEMV bar against the float64 product (bias added before the one rounding, as F.linear does)."""
+    packed, am, w = wide_case(M, K)
+    rng = np.random.default_rng(B * 7 + K + cfg)
+    x = rng.standard_normal((B, K)).astype(np.float32)
+    bias = rng.standard_normal(M).astype(np.float32) * 0.1
+    x_t, b_t = torch_values(x, dtype), torch_values(bias, dtype)
+    P, A = to_dev(packed), to_dev(am)
+    hipabi.set_variant("gemm_wide", cfg)
+    try:
+        y = hipabi.gemm_small(x_t, P, A, M, K, 64, bias=b_t)
+    finally:
+        hipabi.set_variant("gemm_wide", -1)
+    xv = x_t.float().cpu().numpy().astype(np.float64)
+    bv = b_t.float().cpu().numpy().astype(np.float64)
+    exact = xv @ w.T + bv  # float64 product of the exact f32 weights: the oracle's gemv_f64, all rows at once
+    spot = c_oracle.gemv_f64(xv[B - 1], packed, am, M, K, 64) + bv
+    assert np.allclose(exact[B - 1], spot, rtol=1e-12, atol=1e-12)
+    scale = np.abs(xv) @ np.abs(w).T + np.abs(bv)
+    err = np.abs(y.float().cpu().numpy().astype(np.float64) - exact)
+    assert (err <= HALF_ULP[dtype] * 1.01 * np.abs(exact) + 1e-5 * scale + 1e-30).all(), float(err.max())
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_wide_batch_default_dispatch_and_row_limits(dtype):
+    """Default dispatch: 17..64 rows take the one-pass kernel (the result differs from the 16-row launches only in summation
+    order: both within the bar, so about one ulp apart at most); 65..128 rows are split into two even chunks of at most 64;
+    129 rows are refused."""
+    M, K = 4096, 4096
+    packed, am, _ = make_case(M, K, seed=5)
+    P, A = to_dev(packed), to_dev(am)
+    rng = np.random.default_rng(11)
+    x_t = torch_values(rng.standard_normal((128, K)).astype(np.float32), dtype)
+    y48 = hipabi.gemm_small(x_t[:48].contiguous(), P, A, M, K, 64)
+    hipabi.set_variant("gemm_wide", 0)
+    try:
+        y48_chunked = hipabi.gemm_small(x_t[:48].contiguous(), P, A, M, K, 64)
+    finally:
+        hipabi.set_variant("gemm_wide", -1)
+    a, b = y48.float(), y48_chunked.float()
+    assert float((a == b).float().mean()) > 0.9  # mostly the same bits; elsewhere one ulp (more only where the sum cancels)
+    assert torch.allclose(a, b, rtol=4 * HALF_ULP[dtype], atol=1e-4 * float(a.abs().max()))
+    y100 = hipabi.gemm_small(x_t[:100].contiguous(), P, A, M, K, 64)
+    assert torch.equal(y100[:50], hipabi.gemm_small(x_t[:50].contiguous(), P, A, M, K, 64))
+    assert torch.equal(y100[50:], hipabi.gemm_small(x_t[50:100].contiguous(), P, A, M, K, 64))
+    too_many = torch.zeros(129, K, dtype=dtype, device=dev())
     assert hipabi.gemm_small(too_many, P, A, M, K, 64, expect_ok=False) == hipabi.ERR_INVALID
 
 

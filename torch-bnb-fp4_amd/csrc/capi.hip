@@ -15,6 +15,7 @@ thread_local char g_last_error[512] = "";
 void set_dequant_variant(int v);
 void set_gemv_variant(int v);
 void set_small_variant(int v);
+void set_wide_variant(int v);
 void set_quantize_variant(int v);
 
 void set_error(const char *fmt, ...) {
@@ -77,6 +78,10 @@ extern "C" int fp4_hip_set_variant(const char *kernel, int variant) {
     }
     if (kernel && !std::strcmp(kernel, "gemm_small")) {
         fp4::set_small_variant(variant);
+        return FP4_OK;
+    }
+    if (kernel && !std::strcmp(kernel, "gemm_wide")) {
+        fp4::set_wide_variant(variant);
         return FP4_OK;
     }
     fp4::set_error("fp4_hip_set_variant: unknown kernel '%s'", kernel ? kernel : "(null)");

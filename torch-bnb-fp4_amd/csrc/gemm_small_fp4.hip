@@ -715,11 +715,13 @@ void set_small_variant(int v) {
 }  // namespace fp4
 
 namespace fp4 {
+int gemm_wide_launch(int dtype, const void *x, const uint8_t *W, const float *absmax, const void *bias, const void *residual, void *out,
+                     int B, int M, int K, int mode, hipStream_t stream);  // gemm_wide_fp4.hip
 namespace {
 int gemm_small_entry(const void *x, const uint8_t *packed, const float *absmax, const void *bias, const void *residual, void *out,
                      int64_t B, int64_t M, int64_t K, int blocksize, int dtype, int mode, void *stream) {
-    if (B < 1 || B > 64 || M < 0 || K <= 0) {
-        set_error("fp4_hip_gemm_small: B=%lld M=%lld K=%lld (need 1 <= B <= 64)", (long long)B, (long long)M, (long long)K);
+    if (B < 1 || B > 128 || M < 0 || K <= 0) {
+        set_error("fp4_hip_gemm_small: B=%lld M=%lld K=%lld (need 1 <= B <= 128)", (long long)B, (long long)M, (long long)K);
         return FP4_ERR_INVALID_ARGUMENT;
     }
     if ((mode & kModeSiluMulPairs) && (M & 1)) {
@@ -728,14 +730,20 @@ int gemm_small_entry(const void *x, const uint8_t *packed, const float *absmax, 
     }
     const int64_t M_out = (mode & kModeSiluMulPairs) ? M / 2 : M;
     if (B > 16) {
-        // one launch covers 16 activation rows (the matrix-core tile); more rows are evenly split over several launches,
-        // each streaming the weight once - still ahead of dequant + GEMM while launches x 9.45 MB < the 76 MB the
-        // dequantised weight costs to write and read back
         if (dtype != FP4_DTYPE_F16 && dtype != FP4_DTYPE_BF16) {
             set_error("fp4_hip_gemm_small: more than 16 rows need a 16-bit dtype, got %d", dtype);
             return FP4_ERR_UNSUPPORTED;
         }
-        const int64_t chunks = (B + 15) / 16, per = (B + chunks - 1) / chunks;
+        // 17..64 rows: one pass over the weight with 2..4 column tiles per decoded fragment (gemm_wide_fp4.hip) where the shape
+        // allows; otherwise, and above 64 rows, the rows are split evenly over several launches, each streaming the weight once -
+        // still ahead of dequant + GEMM while launches x 9.45 MB < the 76 MB the dequantised weight costs to write and read back
+        const uintptr_t al = reinterpret_cast<uintptr_t>(packed) | reinterpret_cast<uintptr_t>(x);
+        if (B <= 64 && M > 0 && x && packed && absmax && out && blocksize == 64 && (al & 15u) == 0 && M <= (int64_t(1) << 30) &&
+            K <= (int64_t(1) << 24) &&
+            gemm_wide_launch(dtype, x, packed, absmax, bias, residual, out, (int)B, (int)M, (int)K, mode, static_cast<hipStream_t>(stream)) == FP4_OK)
+            return check_launch("fp4_hip_gemm_small");
+        const int64_t unit = B > 64 ? 64 : 16;
+        const int64_t chunks = (B + unit - 1) / unit, per = (B + chunks - 1) / chunks;
         for (int64_t b0 = 0; b0 < B; b0 += per) {
             const int64_t nb = B - b0 < per ? B - b0 : per;
             const int rc = gemm_small_entry(static_cast<const uint8_t *>(x) + size_t(b0) * size_t(K) * 2, packed, absmax, bias,

@@ -1,0 +1,459 @@
+// 17..64 activation rows against one FP4 weight in ONE pass over the weight (gfx950 / MI355X):
+//     out[b][r] = T( sum_k x[b][k] * code[nib(r,k)] * absmax[(r*K+k)/64] + bias[r] )
+// The reference sends every batch > 1 through a full dequant + dense GEMM (torch_bnb_fp4/__init__.py:423-436,616-617): at
+// 14336 x 4096 that is 150 MB written and read back for 33 MB of weight.  gemm_small_fp4.hip covers up to 16 rows per launch
+// (one 16-column matrix-core tile, x in registers); above that it used to stream the weight once per 16 rows.  Here one launch
+// multiplies every decoded weight fragment with NT = 2..4 column tiles of x:
+//   * the 8 waves of a workgroup are WR row groups x WK = 8 / WR K slices; a wave owns RT 16-row tiles and every WK-th quant block;
+//   * per step (one 64-column quant block per K slice) the x operand - 16*NT columns x 128 B, L2-resident, by far the larger
+//     on-chip stream - goes into LDS in full 128-byte lines by LDS-DMA (global_load_lds_dwordx4, no VGPR staging), two ring
+//     slots per K slice; the image is lane-linear, so the bank swizzle (16-byte unit ^ (column >> 1)) is applied to the SOURCE
+//     address and again to the ds_read_b128 address;
+//   * the weight fragment (8 bytes per lane, already in the MFMA operand layout) and its block scale are ordinary loads one
+//     step ahead; x is the A operand and the weight the B operand, so a lane's accumulators all belong to ONE weight row and the
+//     block scale is one scalar per lane;
+//   * decode8's (e0,e2)(e4,e6)(e1,e3)(e5,e7) pairs are put back into natural order (4 v_perm per 8 weights, amortised over the
+//     NT column tiles), so the x image needs no re-pairing;
+//   * K-slice partials meet in LDS (the ring's storage, after the loop) and are summed in a fixed order: deterministic.
+#include <atomic>
+
+#include "gemv_common.h"
+
+#ifndef FP4_WIDE_ABL
+#define FP4_WIDE_ABL 0  // tools/exp_wide.hip only: 1 = no x DMA, 2 = no weight / scale loads (timing ablations; results are wrong)
+#endif
+
+namespace fp4 {
+
+namespace {
+
+typedef __bf16 bf16x8w_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8w_t __attribute__((ext_vector_type(8)));
+
+template <int DT>
+__device__ __forceinline__ f32x4 mfma_xw(u32x4 xfrag, u32x4 wfrag, f32x4 c) {
+    if constexpr (DT == FP4_DTYPE_F16)
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8w_t, xfrag), __builtin_bit_cast(f16x8w_t, wfrag), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8w_t, xfrag), __builtin_bit_cast(bf16x8w_t, wfrag), c, 0, 0, 0);
+}
+
+// 8 weights of one packed dword as 12*code in natural order: (e0,e1) (e2,e3) (e4,e5) (e6,e7)
+template <int DT>
+__device__ __forceinline__ u32x4 decode8_natural(uint32_t q) {
+    uint32_t P[4];
+    decode8<DT>(q, P);
+    u32x4 n;
+    n.x = perm(P[2], P[0], 0x05040100u);
+    n.y = perm(P[2], P[0], 0x07060302u);
+    n.z = perm(P[3], P[1], 0x05040100u);
+    n.w = perm(P[3], P[1], 0x07060302u);
+    return n;
+}
+
+__device__ __forceinline__ void lds_dma16(const uint8_t *src, uint8_t *lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+}
+
+// K-slice partials -> LDS (the ring's storage; the caller has synchronised) -> fixed-order sum -> store.
+// D layout: lane (j = lane & 15 -> weight row of the tile, lane >> 4) register g -> activation row nt*16 + (lane >> 4)*4 + g
+template <int DT, int NT, int RT, int WR>
+__device__ __forceinline__ void wide_epilogue(uint8_t *s_raw, const f32x4 (&acc)[RT][NT], const uint16_t *bias, const uint16_t *residual,
+                                              uint16_t *out, int B, int M, int row0, int mode) {
+    constexpr int WK = 8 / WR, kTiles = WR * RT;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave % WR, wk = wave / WR;
+    float *s_part = reinterpret_cast<float *>(s_raw);  // [WK][kTiles][NT][256]
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+            *reinterpret_cast<f32x4 *>(s_part + ((wk * kTiles + wr * RT + rt) * NT + nt) * 256 + lane * 4) = acc[rt][nt];
+    __syncthreads();
+    const bool pairs = (mode & kModeSiluMulPairs) != 0;
+    for (int o = tid; o < kTiles * NT * 256; o += 512) {
+        // 16 consecutive threads store 16 consecutive weight rows of one activation row
+        const int j = o & 15, nl = (o >> 4) & 15, nt = (o >> 8) % NT, tl = o / (256 * NT);
+        const int e = (((nl >> 2) * 16 + j) << 2) + (nl & 3);
+        const int n = nt * 16 + nl, row = row0 + tl * 16 + j;
+        if (row >= M || n >= B) continue;
+        const float *src = s_part + (tl * NT + nt) * 256 + e;
+        float t = 0.0f;
+#pragma unroll
+        for (int w = 0; w < WK; ++w) t += src[w * kTiles * NT * 256];
+        if (pairs) {  // rows (2p, 2p+1) = (gate, up): neighbouring lanes j, j+1 -> elements e, e+4
+            if (j & 1) continue;
+            float u = 0.0f;
+#pragma unroll
+            for (int w = 0; w < WK; ++w) u += src[w * kTiles * NT * 256 + 4];
+            store_small_silu_mul<DT>(out, bias, residual, n, row >> 1, M >> 1, t * (1.0f / 12.0f), u * (1.0f / 12.0f));
+        } else {
+            store_small<DT>(out, bias, residual, n, row, M, t * (1.0f / 12.0f));
+        }
+    }
+}
+
+template <int DT, int NT, int RT, int WR, int SU>
+__global__ __launch_bounds__(512) void gemm16_wide_kernel(const uint16_t *__restrict__ x, const uint8_t *__restrict__ W,
+                                                          const float *__restrict__ absmax, const uint16_t *__restrict__ bias,
+                                                          const uint16_t *residual, uint16_t *out, int B, int M, int K, int mode) {
+    constexpr int WK = 8 / WR;
+    constexpr int kTiles = WR * RT;              // 16-row tiles per workgroup
+    constexpr int kSlot = NT * 2048;             // one quant block of x: 16*NT columns x 128 B
+    constexpr int kRing = 2 * WK * kSlot;
+    constexpr int kPart = WK * kTiles * NT * 1024;
+    constexpr int kDma = (2 * NT + WR - 1) / WR;  // LDS-DMA instructions (8 columns x 128 B each) per wave and step
+    static_assert(8 % WR == 0, "row groups x K slices = 8 waves");
+    __shared__ __attribute__((aligned(1024))) uint8_t s_raw[kRing > kPart ? kRing : kPart];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave % WR, wk = wave / WR;
+    const int i = lane & 15, kb = lane >> 4;
+    const int row0 = blockIdx.x * (16 * kTiles);
+    const int nblk = K >> 6, steps = nblk / WK;
+
+    // weight / scale streams of this lane: row (tile, i), 8 bytes at kb*8 of every WK-th block
+    const u32x2 *wp[RT];
+    const float *ap[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        const int r = row0 + (wr * RT + rt) * 16 + i;
+        const int64_t row = r < M ? r : M - 1;  // rows past M are computed, never stored
+        wp[rt] = reinterpret_cast<const u32x2 *>(W) + ((row * K) >> 4) + kb;
+        ap[rt] = absmax + row * nblk;
+    }
+    // x image: DMA q of this wave fills columns 8q .. 8q+7 of the slice's slot; lane -> (column, 16-byte slot); the slot holds
+    // source unit slot ^ (column >> 1 & 7)
+    uint32_t xoff[kDma];
+#pragma unroll
+    for (int d = 0; d < kDma; ++d) {
+        const int q = wr + d * WR;
+        const int n = 8 * q + (lane >> 3), sl = lane & 7;
+        const int nn = n < B ? n : B - 1;  // columns past the batch repeat a real one: results never stored
+        xoff[d] = (uint32_t)nn * (uint32_t)K * 2u + (uint32_t)((sl ^ ((n >> 1) & 7)) * 16);
+    }
+    const uint8_t *xb = reinterpret_cast<const uint8_t *>(x);
+    // fragment reads: column nt*16 + i, unit 2*kb + t
+    const int xrd0 = i * 128 + (((2 * kb) ^ (i >> 1)) * 16), xrd1 = i * 128 + (((2 * kb + 1) ^ (i >> 1)) * 16);
+
+    f32x4 acc[RT][NT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[rt][nt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+    auto issue_x = [&](int s) {
+        const int jb = s * WK + wk;
+        uint8_t *slot = s_raw + ((s & 1) * WK + wk) * kSlot;
+#pragma unroll
+        for (int d = 0; d < kDma; ++d)
+            if (!(FP4_WIDE_ABL & 1) && ((2 * NT) % WR == 0 || wr + d * WR < 2 * NT))  // wave-uniform
+                lds_dma16(xb + xoff[d] + (uint32_t)jb * 128u, slot + (wr + d * WR) * 1024);
+    };
+    auto load_w = [&](int s, u32x2 (&wq)[RT], float (&am)[RT]) {
+        const int jb = s * WK + wk;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            if constexpr (FP4_WIDE_ABL & 2) {
+                wq[rt] = u32x2{(uint32_t)jb * 0x01010101u, (uint32_t)lane}, am[rt] = 1.0f;
+            } else {
+                if constexpr (FP4_WIDE_ABL & 4)
+                    wq[rt] = wp[rt][4 * jb];
+                else
+                    wq[rt] = __builtin_nontemporal_load(wp[rt] + 4 * jb);
+                am[rt] = ap[rt][jb];
+            }
+        }
+    };
+    auto compute = [&](int s, const u32x2 (&wq)[RT], const float (&am)[RT]) {
+        const uint8_t *xs = s_raw + ((s & 1) * WK + wk) * kSlot;
+        f32x4 tile[RT][NT];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            u32x4 wf[RT];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) wf[rt] = decode8_natural<DT>(t == 0 ? wq[rt].x : wq[rt].y);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const u32x4 xf = *reinterpret_cast<const u32x4 *>(xs + nt * 2048 + (t == 0 ? xrd0 : xrd1));
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+                    tile[rt][nt] = mfma_xw<DT>(xf, wf[rt], t == 0 ? f32x4{0.0f, 0.0f, 0.0f, 0.0f} : tile[rt][nt]);
+            }
+        }
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                acc[rt][nt].x = __builtin_fmaf(tile[rt][nt].x, am[rt], acc[rt][nt].x);
+                acc[rt][nt].y = __builtin_fmaf(tile[rt][nt].y, am[rt], acc[rt][nt].y);
+                acc[rt][nt].z = __builtin_fmaf(tile[rt][nt].z, am[rt], acc[rt][nt].z);
+                acc[rt][nt].w = __builtin_fmaf(tile[rt][nt].w, am[rt], acc[rt][nt].w);
+            }
+    };
+    if constexpr (SU > 0) {
+        // Resident weights (RT = 1 only, and the dispatcher guarantees steps == SU, i.e. K = 4096): this wave's whole weight / scale stream - 8 + 4 bytes per lane,
+        // tile and step - is requested before the first step and waited for once, with everything in flight at the same time (what
+        // the batch-1 GEMV does).  A load issued one step ahead inside the loop cannot be deeper than that step: the LDS-DMA of x
+        // shares the in-order load counter, and waiting for x retires every older load with it.
+        u32x2 wres[SU][RT];
+        float ares[SU][RT];
+#pragma unroll
+        for (int u = 0; u < SU; ++u) load_w(u, wres[u], ares[u]);
+        issue_x(0);
+#pragma unroll
+        for (int u = 0; u < SU; ++u) {
+            __syncthreads();
+            if (u + 1 < SU) issue_x(u + 1);
+            compute(u, wres[u], ares[u]);
+        }
+    } else {
+        u32x2 wq_n[RT];
+        float am_n[RT];
+        load_w(0, wq_n, am_n);
+        issue_x(0);
+        for (int s = 0; s < steps; ++s) {
+            __syncthreads();  // step s has landed (every wave waits for its own DMAs first); slot (s+1)&1 is free again
+            u32x2 wq[RT];
+            float am[RT];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) wq[rt] = wq_n[rt], am[rt] = am_n[rt];
+            if (s + 1 < steps) {  // uniform
+                issue_x(s + 1);
+                load_w(s + 1, wq_n, am_n);
+            }
+            compute(s, wq, am);
+        }
+    }
+    __syncthreads();  // every wave is done with the ring before the partials overwrite it
+    wide_epilogue<DT, NT, RT, WR>(s_raw, acc, bias, residual, out, B, M, row0, mode);
+}
+
+// ---- tall weights: every global stream by LDS-DMA, the weight stream seven steps deep --------------------------------------
+// Fragment-shaped weight loads (8 bytes per lane from 16 different rows) keep the texture path busy for four cache-line lookups
+// per quad, and a load issued inside the step loop can only be one step deep (above).  Here WR = 2, WK = 4 and
+//   * per step the workgroup's 32*RT rows x 128 B of weight (the four K slices' blocks are one full line per row) and their
+//     32*RT x 4 scales are fetched by waves 4..7 with LDS-DMA in full lines into a ring of kDw steps; these waves issue nothing
+//     else, so a counted s_waitcnt vmcnt leaves kDw - 2 steps of weight in flight across every barrier;
+//   * the x image of step s + 1 is fetched by waves 0..3 (wave w: K slice w), whose counter holds nothing else: vmcnt(0);
+//   * the barrier is the bare s_barrier (a __syncthreads() fence would drain every wave's counter);
+//   * weight image: [row][128 B] with 16-byte piece ^ (row >> 1 & 7), applied to the DMA's source and to the ds_read_b64.
+constexpr int kDw = 8;
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int DT, int NT, int RT>
+__global__ __launch_bounds__(512) void gemm16_wide_ring_kernel(const uint16_t *__restrict__ x, const uint8_t *__restrict__ W,
+                                                               const float *__restrict__ absmax, const uint16_t *__restrict__ bias,
+                                                               const uint16_t *residual, uint16_t *out, int B, int M, int K, int mode) {
+    constexpr int WR = 2, WK = 4, kTiles = WR * RT, kRows = 16 * kTiles;
+    constexpr int kSlot = NT * 2048, kXRing = 2 * WK * kSlot;
+    constexpr int kWSlot = kRows * 128, kSSlot = kRows * 16;
+    constexpr int kPart = WK * kTiles * NT * 1024;
+    constexpr int kXBytes = kXRing > kPart ? kXRing : kPart;
+    constexpr int kWDma = kRows / 8 / 4;   // weight DMAs (8 rows x 128 B) per loader wave and step: 2 (RT = 2) or 1
+    constexpr int kPerStep = kWDma + 1;    // + one scale DMA (4 bytes per lane: 16 rows x 4 scales, or 8 rows with half the lanes)
+    __shared__ __attribute__((aligned(1024))) uint8_t s_raw[kXBytes + kDw * (kWSlot + kSSlot)];
+    uint8_t *s_w = s_raw + kXBytes, *s_s = s_w + kDw * kWSlot;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave % WR, wk = wave / WR;
+    const int i = lane & 15, kb = lane >> 4;
+    const int row0 = blockIdx.x * kRows;
+    const int nblk = K >> 6, steps = nblk / WK;
+    const bool loader = wave >= 4;  // wave-uniform
+
+    // x: wave w < 4 fills K slice w: DMA d -> columns 8d .. 8d+7
+    uint32_t xoff[2 * NT];
+#pragma unroll
+    for (int d = 0; d < 2 * NT; ++d) {
+        const int n = 8 * d + (lane >> 3), sl = lane & 7;
+        const int nn = n < B ? n : B - 1;
+        xoff[d] = (uint32_t)nn * (uint32_t)K * 2u + (uint32_t)((sl ^ ((n >> 1) & 7)) * 16);
+    }
+    const uint8_t *xb = reinterpret_cast<const uint8_t *>(x);
+    // weights: loader wave v = wave - 4, DMA d -> rows 8*(v*kWDma + d) .. +7 of the workgroup; lane -> (row, 16-byte piece)
+    const uint8_t *wsrc[kWDma];
+#pragma unroll
+    for (int d = 0; d < kWDma; ++d) {
+        const int rl = 8 * (((wave - 4) & 3) * kWDma + d) + (lane >> 3), sl = lane & 7;
+        const int r = row0 + rl;
+        const int64_t row = r < M ? r : M - 1;
+        wsrc[d] = W + row * (int64_t)(K >> 1) + ((sl ^ ((rl >> 1) & 7)) * 16);
+    }
+    // scales: lane -> (row, K slice); RT = 2: 16 rows per loader wave, RT = 1: 8 rows (lanes 0..31)
+    constexpr int kSRows = kRows / 4;
+    const int srl = ((wave - 4) & 3) * kSRows + (lane >> 2);
+    const int srow = row0 + srl;
+    const float *ssrc = absmax + (int64_t)(srow < M ? srow : M - 1) * nblk + (lane & 3);
+    const bool slane = (lane >> 2) < kSRows;
+
+    // fragment reads
+    const int xrd0 = i * 128 + (((2 * kb) ^ (i >> 1)) * 16), xrd1 = i * 128 + (((2 * kb + 1) ^ (i >> 1)) * 16);
+    int wrd[RT], srd[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        const int rl = (wr * RT + rt) * 16 + i;
+        wrd[rt] = rl * 128 + (((2 * wk + (kb >> 1)) ^ ((rl >> 1) & 7)) * 16) + (kb & 1) * 8;
+        srd[rt] = rl * 16 + wk * 4;
+    }
+
+    f32x4 acc[RT][NT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[rt][nt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+    auto issue_x = [&](int s) {  // waves 0..3
+        uint8_t *slot = s_raw + ((s & 1) * WK + wave) * kSlot;
+#pragma unroll
+        for (int d = 0; d < 2 * NT; ++d) lds_dma16(xb + xoff[d] + (uint32_t)(s * WK + wave) * 128u, slot + d * 1024);
+    };
+    auto issue_w = [&](int s) {  // waves 4..7
+        const int ring = s % kDw;
+#pragma unroll
+        for (int d = 0; d < kWDma; ++d)
+            lds_dma16(wsrc[d] + s * 128, s_w + ring * kWSlot + (((wave - 4) & 3) * kWDma + d) * 1024);
+        if (slane)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ssrc + s * 4),
+                                             (__attribute__((address_space(3))) void *)(s_s + ring * kSSlot + ((wave - 4) & 3) * kSRows * 16),
+                                             4, 0, 0);
+    };
+    if (loader) {
+        for (int s = 0; s < kDw - 1 && s < steps; ++s) issue_w(s);
+    } else {
+        issue_x(0);
+    }
+    for (int s = 0; s < steps; ++s) {
+        // step s has landed: the x wave's only outstanding DMAs are step s's; a loader wave may keep the kDw - 2 younger steps in flight
+        if (loader && s + kDw - 2 < steps)
+            wait_vmcnt<(kDw - 2) * kPerStep>();
+        else
+            wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (loader) {
+            if (s + kDw - 1 < steps) issue_w(s + kDw - 1);  // into the slot step s - 1 used
+        } else if (s + 1 < steps) {
+            issue_x(s + 1);
+        }
+        const uint8_t *xs = s_raw + ((s & 1) * WK + wk) * kSlot;
+        const uint8_t *ws = s_w + (s % kDw) * kWSlot;
+        const uint8_t *ss = s_s + (s % kDw) * kSSlot;
+        u32x2 wq[RT];
+        float am[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            wq[rt] = *reinterpret_cast<const u32x2 *>(ws + wrd[rt]);
+            am[rt] = *reinterpret_cast<const float *>(ss + srd[rt]);
+        }
+        f32x4 tile[RT][NT];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            u32x4 wf[RT];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) wf[rt] = decode8_natural<DT>(t == 0 ? wq[rt].x : wq[rt].y);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const u32x4 xf = *reinterpret_cast<const u32x4 *>(xs + nt * 2048 + (t == 0 ? xrd0 : xrd1));
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+                    tile[rt][nt] = mfma_xw<DT>(xf, wf[rt], t == 0 ? f32x4{0.0f, 0.0f, 0.0f, 0.0f} : tile[rt][nt]);
+            }
+        }
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                acc[rt][nt].x = __builtin_fmaf(tile[rt][nt].x, am[rt], acc[rt][nt].x);
+                acc[rt][nt].y = __builtin_fmaf(tile[rt][nt].y, am[rt], acc[rt][nt].y);
+                acc[rt][nt].z = __builtin_fmaf(tile[rt][nt].z, am[rt], acc[rt][nt].z);
+                acc[rt][nt].w = __builtin_fmaf(tile[rt][nt].w, am[rt], acc[rt][nt].w);
+            }
+    }
+    __syncthreads();  // every wave is done with the rings before the partials overwrite the x ring's storage
+    wide_epilogue<DT, NT, RT, WR>(s_raw, acc, bias, residual, out, B, M, row0, mode);
+}
+
+std::atomic<int> g_wide_cfg{-1};  // -1 heuristic; 0 = never (16-row launches); 1..5 = (RT, WR) in {(1,1), (2,1), (2,2), (2,4), (1,2)}; +8 = streaming loop
+
+template <int DT, int NT, int RT, int WR, int SU>
+int launch_wide(const void *x, const uint8_t *W, const float *absmax, const void *bias, const void *residual, void *out, int B, int M,
+                int K, int mode, hipStream_t stream) {
+    const unsigned blocks = (unsigned)((M + 16 * RT * WR - 1) / (16 * RT * WR));
+    hipLaunchKernelGGL((gemm16_wide_kernel<DT, NT, RT, WR, SU>), dim3(blocks), dim3(512), 0, stream,
+                       reinterpret_cast<const uint16_t *>(x), W, absmax, reinterpret_cast<const uint16_t *>(bias),
+                       reinterpret_cast<const uint16_t *>(residual), reinterpret_cast<uint16_t *>(out), B, M, K, mode);
+    return FP4_OK;
+}
+
+template <int DT, int NT>
+int dispatch_wide_cfg(int cfg, const void *x, const uint8_t *W, const float *absmax, const void *bias, const void *residual, void *out,
+                      int B, int M, int K, int mode, hipStream_t stream) {
+    const int nblk = K >> 6;
+    const bool resident = (cfg & 8) == 0;  // bit 3 of the sweep hook forces the streaming loop
+#define FP4_WIDE(RT_, WR_, SU_) return launch_wide<DT, NT, RT_, WR_, SU_>(x, W, absmax, bias, residual, out, B, M, K, mode, stream)
+    switch (cfg & 7) {
+        case 1:
+            if (resident && nblk == 64) FP4_WIDE(1, 1, 8);
+            FP4_WIDE(1, 1, 0);
+        case 2:
+            FP4_WIDE(2, 1, 0);
+        case 3:
+            FP4_WIDE(2, 2, 0);
+        case 5:
+            FP4_WIDE(1, 2, 0);
+        case 6:
+        case 7: {
+            constexpr int RTc = 2;
+            (void)RTc;
+            const unsigned rows = (cfg & 7) == 6 ? 64u : 32u;
+            const unsigned blocks = ((unsigned)M + rows - 1) / rows;
+            if ((cfg & 7) == 6)
+                hipLaunchKernelGGL((gemm16_wide_ring_kernel<DT, NT, 2>), dim3(blocks), dim3(512), 0, stream,
+                                   reinterpret_cast<const uint16_t *>(x), W, absmax, reinterpret_cast<const uint16_t *>(bias),
+                                   reinterpret_cast<const uint16_t *>(residual), reinterpret_cast<uint16_t *>(out), B, M, K, mode);
+            else
+                hipLaunchKernelGGL((gemm16_wide_ring_kernel<DT, NT, 1>), dim3(blocks), dim3(512), 0, stream,
+                                   reinterpret_cast<const uint16_t *>(x), W, absmax, reinterpret_cast<const uint16_t *>(bias),
+                                   reinterpret_cast<const uint16_t *>(residual), reinterpret_cast<uint16_t *>(out), B, M, K, mode);
+            return FP4_OK;
+        }
+        default: FP4_WIDE(2, 4, 0);
+    }
+#undef FP4_WIDE
+}
+
+template <int DT>
+int dispatch_wide(int cfg, const void *x, const uint8_t *W, const float *absmax, const void *bias, const void *residual, void *out, int B,
+                  int M, int K, int mode, hipStream_t stream) {
+    const int nt = (B + 15) / 16;
+    if (nt == 2) return dispatch_wide_cfg<DT, 2>(cfg, x, W, absmax, bias, residual, out, B, M, K, mode, stream);
+    if (nt == 3) return dispatch_wide_cfg<DT, 3>(cfg, x, W, absmax, bias, residual, out, B, M, K, mode, stream);
+    return dispatch_wide_cfg<DT, 4>(cfg, x, W, absmax, bias, residual, out, B, M, K, mode, stream);
+}
+
+}  // namespace
+
+void set_wide_variant(int v) { g_wide_cfg = v < 0 ? -1 : (v & 15); }
+
+// 17..64 activation rows, 16-bit dtype, blocksize 64, K % 512 == 0, 16-byte aligned operands.  Returns FP4_OK after the launch, or
+// -1 when the shape is not covered / the path is switched off (the caller then streams the weight once per 16 rows).
+int gemm_wide_launch(int dtype, const void *x, const uint8_t *W, const float *absmax, const void *bias, const void *residual, void *out,
+                     int B, int M, int K, int mode, hipStream_t stream) {
+    int cfg = g_wide_cfg.load(std::memory_order_relaxed);
+    if (cfg == 0 || B <= 16 || B > 64 || (K % 512) != 0 || M < 1) return -1;
+    if ((uint64_t)B * (uint64_t)K * 2u >= (uint64_t(1) << 32)) return -1;  // 32-bit x offsets
+    if (cfg < 0) {
+        // rows per workgroup: 16 while that still fills the chip once, 64 (x shared by two row groups, each weight fragment used for
+        // two tiles' worth of columns) from there on, 128 on very tall weights
+        const int cus = device_cu_count();
+        cfg = M <= 16 * cus + 16 * cus / 2 ? 1 : (M <= 128 * cus ? 3 : 4);
+    }
+    return dtype == FP4_DTYPE_F16 ? dispatch_wide<FP4_DTYPE_F16>(cfg, x, W, absmax, bias, residual, out, B, M, K, mode, stream)
+                                  : dispatch_wide<FP4_DTYPE_BF16>(cfg, x, W, absmax, bias, residual, out, B, M, K, mode, stream);
+}
+
+}  // namespace fp4
