@@ -111,22 +111,24 @@ FP4_HIP_API int fp4_hip_gemv_fused(const void *x, const uint8_t *packed, const f
                        void *out, int64_t M, int64_t K, int blocksize, int dtype, int epilogue, void *stream);
 
 /*
- * Small-batch companion of the GEMV (2..64 activation rows; also accepts 1; one launch per 16 rows):
+ * Small-batch companion of the GEMV (2..128 activation rows; also accepts 1):
  *   out[b][r] = T( sum_k x[b][k] * code[nibble(r,k)] * absmax[(r*K+k)/blocksize] + bias[r] )
  * x is T[B,K] row-major, out T[B,M]; f32 accumulation, ONE rounding, bias added in f32 first (what the
  * reference's batch > 1 path, dequant + F.linear, does - torch_bnb_fp4/__init__.py:423-436,616-617 - without
  * writing and re-reading the M*K dequantised weight).  16-bit dtypes only.  Two kernels: a matrix-core one
  * (v_mfma_f32_16x16x32; blocksize 64, K % 512 == 0; any B <= 16) and a VALU one (B <= 8; K % 32 == 0, K <= 16384,
  * less for larger B; power-of-two blocksize >= 32 dividing K).  Returns FP4_ERR_UNSUPPORTED for shapes neither
- * covers, so the caller can fall back to dequant + GEMM.  17..64 rows are split evenly over ceil(B/16) launches, each
- * streaming the weight once (worth it while that is less traffic than writing and re-reading the dequantised weight:
- * always up to 32 rows, up to 64 on tall weights).
+ * covers, so the caller can fall back to dequant + GEMM.  17..64 rows (blocksize 64, K % 512 == 0): ONE pass over the
+ * weight on the matrix cores with 2..4 column tiles of x per decoded weight fragment (x staged through LDS by LDS-DMA);
+ * where that kernel does not apply the rows are split evenly over ceil(B/16) launches, each streaming the weight once.
+ * 65..128 rows: two even chunks of at most 64.  Measured against dequant + hipBLASLt GEMM on MI355X
+ * (profiles/r02_wide_batch_17_to_128_rows.txt): 1.4-3.1x faster at 17..64 rows, level to 1.5x at 65..128.
  */
 FP4_HIP_API int fp4_hip_gemm_small(const void *x, const uint8_t *packed, const float *absmax, const void *bias, void *out,
                                    int64_t B, int64_t M, int64_t K, int blocksize, int dtype, void *stream);
 
 /*
- * The small-batch product with the fused decode epilogues of fp4_hip_gemv_fused, for 1..64 activation rows (batched decode):
+ * The small-batch product with the fused decode epilogues of fp4_hip_gemv_fused, for 1..128 activation rows (batched decode):
  *   EPILOGUE_NONE:            t = T(sum[b][r] + bias[r]) (F.linear: bias in f32, one rounding); if residual: t = T(t + residual[b][r])
  *                             out : T[B, M], residual : T[B, M].
  *   EPILOGUE_SILU_MUL_PAIRS:  rows interleave gate and up (row 2i / 2i+1): g = T(sum_2i + bias_2i), u = T(sum_2i+1 + bias_2i+1),
@@ -188,8 +190,8 @@ FP4_HIP_API int fp4_hip_quantize_blockwise(const void *w, int w_dtype, uint8_t *
 
 /*
  * Tuning hook for benchmarks/sweeps: selects a kernel geometry by name
- * ("dequant", "gemv", "gemm_small", "quantize" = workgroups per CU of the persistent
- * grid).  variant < 0 (quantize: 0) restores the built-in heuristic.
+ * ("dequant", "gemv", "gemm_small", "gemm_wide" = workgroup shape of the 17..64-row kernel (0 = off),
+ * "quantize" = workgroups per CU of the persistent grid).  variant < 0 (quantize: 0) restores the built-in heuristic.
  * Process-wide (relaxed atomics: safe to flip while other threads launch, each launch
  * reads it once); for sweeps and tests only, not part of the reference surface.
  */

@@ -447,10 +447,19 @@ int gemm_wide_launch(int dtype, const void *x, const uint8_t *W, const float *ab
     if (cfg == 0 || B <= 16 || B > 64 || (K % 512) != 0 || M < 1) return -1;
     if ((uint64_t)B * (uint64_t)K * 2u >= (uint64_t(1) << 32)) return -1;  // 32-bit x offsets
     if (cfg < 0) {
-        // rows per workgroup: 16 while that still fills the chip once, 64 (x shared by two row groups, each weight fragment used for
-        // two tiles' worth of columns) from there on, 128 on very tall weights
+        // Measured (profiles/r02_wide_batch_17_to_128_rows.txt, MI355X): tall weights - 64 rows per workgroup on the all-DMA ring
+        // kernel once that fills three quarters of the chip, 32 rows from half of that; below, 16 rows per workgroup with the
+        // register-resident weight stream (K = 4096) - and there, for K != 4096 and at most 32 rows, two 16-row launches are
+        // still ahead (4096 x 14336 x 32 rows: 34.7 vs 37.3 us).
         const int cus = device_cu_count();
-        cfg = M <= 16 * cus + 16 * cus / 2 ? 1 : (M <= 128 * cus ? 3 : 4);
+        if (M >= 48 * cus)
+            cfg = 6;
+        else if (M >= 24 * cus)
+            cfg = 7;
+        else if (K == 4096 || B > 32)
+            cfg = 1;
+        else
+            return -1;
     }
     return dtype == FP4_DTYPE_F16 ? dispatch_wide<FP4_DTYPE_F16>(cfg, x, W, absmax, bias, residual, out, B, M, K, mode, stream)
                                   : dispatch_wide<FP4_DTYPE_BF16>(cfg, x, W, absmax, bias, residual, out, B, M, K, mode, stream);

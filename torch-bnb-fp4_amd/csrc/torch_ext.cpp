@@ -224,7 +224,7 @@ torch::Tensor gemv_fp4_fused(torch::Tensor A, torch::Tensor B, torch::Tensor abs
     return out;
 }
 
-// fused small-batch product: A [..., K] with 1..16 rows in total -> [..., m]; raises if the shape is not covered
+// fused small-batch product: A [..., K] with 1..128 rows in total -> [..., m]; raises if the shape is not covered
 torch::Tensor gemm_small_fp4(torch::Tensor A, torch::Tensor B, torch::Tensor absmax, int blocksize, std::vector<uint32_t> Bshape,
                              c10::optional<torch::Tensor> bias) {
     check_gpu_contiguous(A, "A");
@@ -234,7 +234,7 @@ torch::Tensor gemm_small_fp4(torch::Tensor A, torch::Tensor B, torch::Tensor abs
     const int64_t m = Bshape[0], k = Bshape[1];
     TORCH_CHECK(A.dim() >= 1 && A.size(-1) == k, "gemm_small_fp4: last dim of the activation must be in_features = ", k);
     const int64_t rows = A.numel() / k;
-    TORCH_CHECK(rows >= 1 && rows <= 64, "gemm_small_fp4 covers 1..64 activation rows, got ", rows);
+    TORCH_CHECK(rows >= 1 && rows <= 128, "gemm_small_fp4 covers 1..128 activation rows, got ", rows);
     TORCH_CHECK(B.dtype() == torch::kUInt8 && B.numel() * 2 >= m * k, "B too small for a ", m, "x", k, " weight");
     TORCH_CHECK(absmax.scalar_type() == torch::kFloat32 && absmax.numel() * int64_t(blocksize) >= m * k, "absmax too small");
     const int dt = to_fp4_dtype(A.scalar_type(), "gemm_small_fp4");
@@ -255,7 +255,7 @@ torch::Tensor gemm_small_fp4(torch::Tensor A, torch::Tensor B, torch::Tensor abs
     return out;
 }
 
-// the small-batch product with the fused epilogues (fp4_hip_gemm_small_fused): A [..., K] with 1..64 rows -> [..., m] or [..., m / 2]
+// the small-batch product with the fused epilogues (fp4_hip_gemm_small_fused): A [..., K] with 1..128 rows -> [..., m] or [..., m / 2]
 torch::Tensor gemm_small_fp4_fused(torch::Tensor A, torch::Tensor B, torch::Tensor absmax, int blocksize, std::vector<uint32_t> Bshape,
                                    c10::optional<torch::Tensor> bias, c10::optional<torch::Tensor> residual, int epilogue) {
     check_gpu_contiguous(A, "A");
@@ -267,7 +267,7 @@ torch::Tensor gemm_small_fp4_fused(torch::Tensor A, torch::Tensor B, torch::Tens
     const int64_t m_out = epilogue == FP4_EPILOGUE_SILU_MUL_PAIRS ? m / 2 : m;
     TORCH_CHECK(A.dim() >= 1 && A.size(-1) == k, "gemm_small_fp4_fused: last dim of the activation must be in_features = ", k);
     const int64_t rows = A.numel() / k;
-    TORCH_CHECK(rows >= 1 && rows <= 64, "gemm_small_fp4_fused covers 1..64 activation rows, got ", rows);
+    TORCH_CHECK(rows >= 1 && rows <= 128, "gemm_small_fp4_fused covers 1..128 activation rows, got ", rows);
     TORCH_CHECK(B.dtype() == torch::kUInt8 && B.numel() * 2 >= m * k, "B too small for a ", m, "x", k, " weight");
     TORCH_CHECK(absmax.scalar_type() == torch::kFloat32 && absmax.numel() * int64_t(blocksize) >= m * k, "absmax too small");
     const int dt = to_fp4_dtype(A.scalar_type(), "gemm_small_fp4_fused");
@@ -419,9 +419,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("gemv_fp4_fused", &gemv_fp4_fused,
           "GEMV with a fused epilogue: (A, B, absmax, blocksize, Bshape, bias|None, residual|None, epilogue) ; epilogue 0 = bias/residual, "
           "1 = silu(gate) * up over interleaved rows");
-    m.def("gemm_small_fp4", &gemm_small_fp4, "fused FP4 product for 1..16 activation rows: (A, B, absmax, blocksize, Bshape, bias|None)");
+    m.def("gemm_small_fp4", &gemm_small_fp4, "fused FP4 product for 1..128 activation rows: (A, B, absmax, blocksize, Bshape, bias|None)");
     m.def("gemm_small_fp4_fused", &gemm_small_fp4_fused,
-          "fused FP4 product for 1..64 rows with an epilogue: (A, B, absmax, blocksize, Bshape, bias|None, residual|None, epilogue)");
+          "fused FP4 product for 1..128 rows with an epilogue: (A, B, absmax, blocksize, Bshape, bias|None, residual|None, epilogue)");
     m.def("gemv_fp4_partial", &gemv_fp4_partial, "f32 partial sums of a K-split shard: (A, B, absmax, blocksize, Bshape)");
     m.def("comm_alloc", &comm_alloc, "(world, capacity, device) -> (buffer address, 64-byte IPC handle, memory kind)");
     m.def("comm_open", &comm_open, "(handle, device) -> mapped address of a peer's buffer");

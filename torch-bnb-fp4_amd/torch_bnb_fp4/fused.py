@@ -11,7 +11,7 @@ GEMV's epilogue (``fp4_hip_gemv_fused``):
   ``silu(gate(x)) * up(x)`` in one launch.
 
 Every intermediate is rounded to the activation dtype exactly where the separate torch ops would round it, so the result
-equals the unfused sequence bit for bit (``exp`` is the device library's, as in torch's silu).  2..32 activation rows
+equals the unfused sequence bit for bit (``exp`` is the device library's, as in torch's silu).  2..128 activation rows
 (batched decode) take the same epilogues on the small-batch kernels (``fp4_hip_gemm_small_fused``); larger inputs, or shapes
 the fused kernels do not cover, run the unfused sequence through :class:`QuantData`.
 """
@@ -137,7 +137,7 @@ class FusedFP4Linear(nn.Module):
                     raise
                 self._fused_ok = False  # shape outside the fused kernel's coverage: unfused sequence from now on
         rows = x.numel() // K if K else 0
-        if (self._small_ok and 2 <= rows <= 32 and K == self.in_features and x.dtype == qd.o_type and x.dtype in (torch.float16, torch.bfloat16)
+        if (self._small_ok and 2 <= rows <= 128 and K == self.in_features and x.dtype == qd.o_type and x.dtype in (torch.float16, torch.bfloat16)
                 and ((qd.blocksize == 64 and K % 512 == 0) or (rows <= 8 and K % qd.blocksize == 0 and K % 32 == 0 and K <= 4096))):
             try:  # batched decode: the same epilogues on the small-batch kernels
                 return ext.gemm_small_fp4_fused(x.contiguous(), qd._B_t, qd.absmax, qd.blocksize, qd._shape_list, qd.bias, residual,

@@ -130,7 +130,7 @@ def recursively_replace_with_fp4_linear(
 
 
 def set_small_batch_fused(module: nn.Module, enabled: bool = True) -> int:
-    """Route 2..32 activation rows of every :class:`TorchFP4Linear` below ``module`` to the fused small-batch kernels
+    """Route 2..128 activation rows of every :class:`TorchFP4Linear` below ``module`` to the fused small-batch kernels
     (``enabled=True``) or back to the reference's dispatch, dequant + GEMM for every batch > 1
     (torch_bnb_fp4/__init__.py:592,616-617; the default, so that a converted model behaves like the reference's).
     Not part of the reference surface.  Returns the number of layers touched.  Batched decode through Mistral-7B shapes:
