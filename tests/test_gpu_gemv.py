@@ -342,7 +342,7 @@ def wide_case(M, K):
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6, 7, 9, 11])  # (row tiles per wave, row groups per workgroup) = (1,1) (2,1) (2,2) (2,4) (1,2); 6, 7: the all-DMA ring kernel with 2 / 1 row tiles; +8: streaming instead of resident weights
-@pytest.mark.parametrize("B", [17, 24, 32, 33, 40, 48, 49, 64])
+@pytest.mark.parametrize("B", [17, 32, 33, 49, 64])
 @pytest.mark.parametrize("M,K", WIDE_SHAPES)
 def test_wide_batch_one_pass_kernel(dtype, cfg, B, M, K):
     """17..64 activation rows in ONE pass over the weight (gemm16_wide_kernel: x through LDS by LDS-DMA, 2..4 column tiles per
