@@ -122,7 +122,7 @@ FP4_HIP_API int fp4_hip_gemv_fused(const void *x, const uint8_t *packed, const f
  * weight on the matrix cores with 2..4 column tiles of x per decoded weight fragment (x staged through LDS by LDS-DMA);
  * where that kernel does not apply the rows are split evenly over ceil(B/16) launches, each streaming the weight once.
  * 65..128 rows: two even chunks of at most 64.  Measured against dequant + hipBLASLt GEMM on MI355X
- * (profiles/r02_wide_batch_17_to_128_rows.txt): 1.4-3.1x faster at 17..64 rows, level to 1.5x at 65..128.
+ * (profiles/r02_wide_batch_17_to_128_rows.txt): 1.7-3.1x faster at 17..64 rows, 1.27-1.6x at 65..128.
  */
 FP4_HIP_API int fp4_hip_gemm_small(const void *x, const uint8_t *packed, const float *absmax, const void *bias, void *out,
                                    int64_t B, int64_t M, int64_t K, int blocksize, int dtype, void *stream);
@@ -190,7 +190,7 @@ FP4_HIP_API int fp4_hip_quantize_blockwise(const void *w, int w_dtype, uint8_t *
 
 /*
  * Tuning hook for benchmarks/sweeps: selects a kernel geometry by name
- * ("dequant", "gemv", "gemm_small", "gemm_wide" = workgroup shape of the 17..64-row kernel (0 = off),
+ * ("dequant", "gemv", "gemm_small", "gemm_wide" = rows per workgroup of the 17..64-row kernels (1 / 2 / 3 = 16 / 32 / 64; 0 = off),
  * "quantize" = workgroups per CU of the persistent grid).  variant < 0 (quantize: 0) restores the built-in heuristic.
  * Process-wide (relaxed atomics: safe to flip while other threads launch, each launch
  * reads it once); for sweeps and tests only, not part of the reference surface.

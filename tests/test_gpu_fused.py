@@ -187,12 +187,12 @@ def test_fused_layers_match_the_unfused_modules_and_capture_into_a_graph():
 
 
 @pytest.mark.parametrize("dtype", DT16)
-@pytest.mark.parametrize("wide", [-1, 0, 1, 3, 6, 7])  # 17..64 rows: default dispatch, 16-row launches, the one-pass kernel's workgroup shapes
+@pytest.mark.parametrize("wide", [-1, 0, 1, 2, 3])  # 17..64 rows: default dispatch, 16-row launches, the one-pass kernels' 16 / 32 / 64-row workgroups
 @pytest.mark.parametrize("B", [24, 40, 64, 100])
 @pytest.mark.parametrize("M,K", [(4096, 4096), (258, 2048), (130, 14336), (66, 1024)])
 def test_wide_batch_epilogues(dtype, wide, B, M, K):
     """The same epilogues on 17..128 rows, on every path those take (the one-pass kernel's epilogue is its own code)."""
-    if wide > 0 and B > 64 and wide != 6:
+    if wide > 0 and B > 64 and wide != 3:
         pytest.skip("above 64 rows the chunks take the same kernels as the 33..64-row cases")
     hipabi.set_variant("gemm_wide", wide)
     try:

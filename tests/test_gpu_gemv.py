@@ -341,13 +341,14 @@ def wide_case(M, K):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6, 7, 9, 11])  # (row tiles per wave, row groups per workgroup) = (1,1) (2,1) (2,2) (2,4) (1,2); 6, 7: the all-DMA ring kernel with 2 / 1 row tiles; +8: streaming instead of resident weights
-@pytest.mark.parametrize("B", [17, 32, 33, 49, 64])
+@pytest.mark.parametrize("cfg", [1, 2, 3])  # 16 / 32 / 64 rows per workgroup
+@pytest.mark.parametrize("B", [17, 24, 32, 33, 40, 48, 49, 64])
 @pytest.mark.parametrize("M,K", WIDE_SHAPES)
 def test_wide_batch_one_pass_kernel(dtype, cfg, B, M, K):
-    """17..64 activation rows in ONE pass over the weight (gemm16_wide_kernel: x through LDS by LDS-DMA, 2..4 column tiles per
-    decoded weight fragment), every workgroup shape forced at every size: ragged M (33, 66, 130, 257, 300: clamped rows, last
-    workgroup partly empty), B not a multiple of 16 (clamped columns), 1..28 steps per K slice.  Every row of the result meets
+    """17..64 activation rows in ONE pass over the weight (gemm16_wide_ring8_kernel / gemm16_wide_ring_kernel: every stream through
+    LDS by LDS-DMA, 2..4 column tiles per decoded weight fragment), every workgroup shape forced at every size: ragged M (33, 66,
+    130, 257, 300: clamped rows, last workgroup partly empty), B not a multiple of 16 (clamped columns), 1..56 steps per K slice
+    (fewer steps than the weight ring is deep, exactly as many, more).  Every row of the result meets
     the GEMV bar against the float64 product (bias added before the one rounding, as F.linear does)."""
     packed, am, w = wide_case(M, K)
     rng = np.random.default_rng(B * 7 + K + cfg)

@@ -1,8 +1,8 @@
-// Timing ablations of the one-pass 17..64-row kernel (csrc/gemm_wide_fp4.hip, included as is): what does a launch cost without
-// the x stream (LDS-DMA), without the weight stream, without both?  No torch.
-// Build (one binary per ablation): hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -DFP4_WIDE_ABL=<0..3>
-//        -Iinclude -Itorch-bnb-fp4_amd/csrc tools/exp_wide.hip -o gpurun_out/exp_wide_<n>
-// Run: exp_wide_<n> M K B   -> us per launch for every workgroup shape, HBM-cold rotation over R weights in a HIP graph
+// The one-pass 17..64-row kernels (csrc/gemm_wide_fp4.hip, included as is) without torch: us per launch for every workgroup shape.
+// (The first version of that file also had a register-staged kernel with compile-time ablation switches - no x DMA, no weight loads;
+// its numbers are in profiles/r02_wide_batch_17_to_128_rows.txt.)
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Iinclude -Itorch-bnb-fp4_amd/csrc tools/exp_wide.hip -o build_tmp/exp/exp_wide
+// Run: exp_wide M K B   -> HBM-cold rotation over R weights in a HIP graph
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -51,8 +51,8 @@ int main(int argc, char **argv) {
     CK(hipMemcpy(x, hx.data(), hx.size() * 2, hipMemcpyHostToDevice));
     hipStream_t s;
     CK(hipStreamCreate(&s));
-    printf("%dx%d, %d rows, ablation %d (1 = no x DMA, 2 = no weight loads):", M, K, B, FP4_WIDE_ABL);
-    for (int cfg : {1, 3, 11, 5, 6, 7}) {
+    printf("%dx%d, %d rows, us per launch by rows per workgroup:", M, K, B);
+    for (int cfg : {1, 2, 3}) {
         fp4::set_wide_variant(cfg);
         auto pass = [&]() {
             for (int i = 0; i < R; ++i)
@@ -79,7 +79,7 @@ int main(int argc, char **argv) {
             CK(hipEventElapsedTime(&ms, e0, e1));
             best = ms < best ? ms : best;
         }
-        printf("  cfg %d%s: %6.2f us", cfg & 7, (cfg & 8) ? "s" : "", best * 1e3f / R);
+        printf("  %d rows: %6.2f", 8 << cfg, best * 1e3f / R);
         CK(hipGraphExecDestroy(ge));
         CK(hipGraphDestroy(g));
     }

@@ -4,24 +4,22 @@
 // 14336 x 4096 that is 150 MB written and read back for 33 MB of weight.  gemm_small_fp4.hip covers up to 16 rows per launch
 // (one 16-column matrix-core tile, x in registers); above that it used to stream the weight once per 16 rows.  Here one launch
 // multiplies every decoded weight fragment with NT = 2..4 column tiles of x:
-//   * the 8 waves of a workgroup are WR row groups x WK = 8 / WR K slices; a wave owns RT 16-row tiles and every WK-th quant block;
+//   * the compute waves of a workgroup are WR row groups x WK K slices; a wave owns RT 16-row tiles and every WK-th quant block;
 //   * per step (one 64-column quant block per K slice) the x operand - 16*NT columns x 128 B, L2-resident, by far the larger
 //     on-chip stream - goes into LDS in full 128-byte lines by LDS-DMA (global_load_lds_dwordx4, no VGPR staging), two ring
 //     slots per K slice; the image is lane-linear, so the bank swizzle (16-byte unit ^ (column >> 1)) is applied to the SOURCE
 //     address and again to the ds_read_b128 address;
-//   * the weight fragment (8 bytes per lane, already in the MFMA operand layout) and its block scale are ordinary loads one
-//     step ahead; x is the A operand and the weight the B operand, so a lane's accumulators all belong to ONE weight row and the
-//     block scale is one scalar per lane;
+//   * the weight and its block scales come by LDS-DMA as well, in full lines, from waves that issue nothing else, into a ring
+//     several steps deep (see the kernels); a first version loaded them fragment-shaped into registers one step ahead and spent
+//     more time on that than on everything else (profiles/r02_wide_batch_17_to_128_rows.txt);
+//   * x is the A operand and the weight the B operand, so a lane's accumulators all belong to ONE weight row and the block scale is
+//     one scalar per lane;
 //   * decode8's (e0,e2)(e4,e6)(e1,e3)(e5,e7) pairs are put back into natural order (4 v_perm per 8 weights, amortised over the
 //     NT column tiles), so the x image needs no re-pairing;
 //   * K-slice partials meet in LDS (the ring's storage, after the loop) and are summed in a fixed order: deterministic.
 #include <atomic>
 
 #include "gemv_common.h"
-
-#ifndef FP4_WIDE_ABL
-#define FP4_WIDE_ABL 0  // tools/exp_wide.hip only: 1 = no x DMA, 2 = no weight / scale loads (timing ablations; results are wrong)
-#endif
 
 namespace fp4 {
 
@@ -58,21 +56,23 @@ __device__ __forceinline__ void lds_dma16(const uint8_t *src, uint8_t *lds_wave_
 
 // K-slice partials -> LDS (the ring's storage; the caller has synchronised) -> fixed-order sum -> store.
 // D layout: lane (j = lane & 15 -> weight row of the tile, lane >> 4) register g -> activation row nt*16 + (lane >> 4)*4 + g
-template <int DT, int NT, int RT, int WR>
+template <int DT, int NT, int RT, int WR, int NTHREADS = 512>
 __device__ __forceinline__ void wide_epilogue(uint8_t *s_raw, const f32x4 (&acc)[RT][NT], const uint16_t *bias, const uint16_t *residual,
                                               uint16_t *out, int B, int M, int row0, int mode) {
     constexpr int WK = 8 / WR, kTiles = WR * RT;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave % WR, wk = wave / WR;
     float *s_part = reinterpret_cast<float *>(s_raw);  // [WK][kTiles][NT][256]
+    if (NTHREADS == 512 || wave < 8) {  // (waves beyond the eighth only load)
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
+        for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-            *reinterpret_cast<f32x4 *>(s_part + ((wk * kTiles + wr * RT + rt) * NT + nt) * 256 + lane * 4) = acc[rt][nt];
+            for (int nt = 0; nt < NT; ++nt)
+                *reinterpret_cast<f32x4 *>(s_part + ((wk * kTiles + wr * RT + rt) * NT + nt) * 256 + lane * 4) = acc[rt][nt];
+    }
     __syncthreads();
     const bool pairs = (mode & kModeSiluMulPairs) != 0;
-    for (int o = tid; o < kTiles * NT * 256; o += 512) {
+    for (int o = tid; o < kTiles * NT * 256; o += NTHREADS) {
         // 16 consecutive threads store 16 consecutive weight rows of one activation row
         const int j = o & 15, nl = (o >> 4) & 15, nt = (o >> 8) % NT, tl = o / (256 * NT);
         const int e = (((nl >> 2) * 16 + j) << 2) + (nl & 3);
@@ -94,144 +94,10 @@ __device__ __forceinline__ void wide_epilogue(uint8_t *s_raw, const f32x4 (&acc)
     }
 }
 
-template <int DT, int NT, int RT, int WR, int SU>
-__global__ __launch_bounds__(512) void gemm16_wide_kernel(const uint16_t *__restrict__ x, const uint8_t *__restrict__ W,
-                                                          const float *__restrict__ absmax, const uint16_t *__restrict__ bias,
-                                                          const uint16_t *residual, uint16_t *out, int B, int M, int K, int mode) {
-    constexpr int WK = 8 / WR;
-    constexpr int kTiles = WR * RT;              // 16-row tiles per workgroup
-    constexpr int kSlot = NT * 2048;             // one quant block of x: 16*NT columns x 128 B
-    constexpr int kRing = 2 * WK * kSlot;
-    constexpr int kPart = WK * kTiles * NT * 1024;
-    constexpr int kDma = (2 * NT + WR - 1) / WR;  // LDS-DMA instructions (8 columns x 128 B each) per wave and step
-    static_assert(8 % WR == 0, "row groups x K slices = 8 waves");
-    __shared__ __attribute__((aligned(1024))) uint8_t s_raw[kRing > kPart ? kRing : kPart];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave % WR, wk = wave / WR;
-    const int i = lane & 15, kb = lane >> 4;
-    const int row0 = blockIdx.x * (16 * kTiles);
-    const int nblk = K >> 6, steps = nblk / WK;
-
-    // weight / scale streams of this lane: row (tile, i), 8 bytes at kb*8 of every WK-th block
-    const u32x2 *wp[RT];
-    const float *ap[RT];
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-        const int r = row0 + (wr * RT + rt) * 16 + i;
-        const int64_t row = r < M ? r : M - 1;  // rows past M are computed, never stored
-        wp[rt] = reinterpret_cast<const u32x2 *>(W) + ((row * K) >> 4) + kb;
-        ap[rt] = absmax + row * nblk;
-    }
-    // x image: DMA q of this wave fills columns 8q .. 8q+7 of the slice's slot; lane -> (column, 16-byte slot); the slot holds
-    // source unit slot ^ (column >> 1 & 7)
-    uint32_t xoff[kDma];
-#pragma unroll
-    for (int d = 0; d < kDma; ++d) {
-        const int q = wr + d * WR;
-        const int n = 8 * q + (lane >> 3), sl = lane & 7;
-        const int nn = n < B ? n : B - 1;  // columns past the batch repeat a real one: results never stored
-        xoff[d] = (uint32_t)nn * (uint32_t)K * 2u + (uint32_t)((sl ^ ((n >> 1) & 7)) * 16);
-    }
-    const uint8_t *xb = reinterpret_cast<const uint8_t *>(x);
-    // fragment reads: column nt*16 + i, unit 2*kb + t
-    const int xrd0 = i * 128 + (((2 * kb) ^ (i >> 1)) * 16), xrd1 = i * 128 + (((2 * kb + 1) ^ (i >> 1)) * 16);
-
-    f32x4 acc[RT][NT];
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[rt][nt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-
-    auto issue_x = [&](int s) {
-        const int jb = s * WK + wk;
-        uint8_t *slot = s_raw + ((s & 1) * WK + wk) * kSlot;
-#pragma unroll
-        for (int d = 0; d < kDma; ++d)
-            if (!(FP4_WIDE_ABL & 1) && ((2 * NT) % WR == 0 || wr + d * WR < 2 * NT))  // wave-uniform
-                lds_dma16(xb + xoff[d] + (uint32_t)jb * 128u, slot + (wr + d * WR) * 1024);
-    };
-    auto load_w = [&](int s, u32x2 (&wq)[RT], float (&am)[RT]) {
-        const int jb = s * WK + wk;
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-            if constexpr (FP4_WIDE_ABL & 2) {
-                wq[rt] = u32x2{(uint32_t)jb * 0x01010101u, (uint32_t)lane}, am[rt] = 1.0f;
-            } else {
-                if constexpr (FP4_WIDE_ABL & 4)
-                    wq[rt] = wp[rt][4 * jb];
-                else
-                    wq[rt] = __builtin_nontemporal_load(wp[rt] + 4 * jb);
-                am[rt] = ap[rt][jb];
-            }
-        }
-    };
-    auto compute = [&](int s, const u32x2 (&wq)[RT], const float (&am)[RT]) {
-        const uint8_t *xs = s_raw + ((s & 1) * WK + wk) * kSlot;
-        f32x4 tile[RT][NT];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            u32x4 wf[RT];
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt) wf[rt] = decode8_natural<DT>(t == 0 ? wq[rt].x : wq[rt].y);
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const u32x4 xf = *reinterpret_cast<const u32x4 *>(xs + nt * 2048 + (t == 0 ? xrd0 : xrd1));
-#pragma unroll
-                for (int rt = 0; rt < RT; ++rt)
-                    tile[rt][nt] = mfma_xw<DT>(xf, wf[rt], t == 0 ? f32x4{0.0f, 0.0f, 0.0f, 0.0f} : tile[rt][nt]);
-            }
-        }
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                acc[rt][nt].x = __builtin_fmaf(tile[rt][nt].x, am[rt], acc[rt][nt].x);
-                acc[rt][nt].y = __builtin_fmaf(tile[rt][nt].y, am[rt], acc[rt][nt].y);
-                acc[rt][nt].z = __builtin_fmaf(tile[rt][nt].z, am[rt], acc[rt][nt].z);
-                acc[rt][nt].w = __builtin_fmaf(tile[rt][nt].w, am[rt], acc[rt][nt].w);
-            }
-    };
-    if constexpr (SU > 0) {
-        // Resident weights (RT = 1 only, and the dispatcher guarantees steps == SU, i.e. K = 4096): this wave's whole weight / scale stream - 8 + 4 bytes per lane,
-        // tile and step - is requested before the first step and waited for once, with everything in flight at the same time (what
-        // the batch-1 GEMV does).  A load issued one step ahead inside the loop cannot be deeper than that step: the LDS-DMA of x
-        // shares the in-order load counter, and waiting for x retires every older load with it.
-        u32x2 wres[SU][RT];
-        float ares[SU][RT];
-#pragma unroll
-        for (int u = 0; u < SU; ++u) load_w(u, wres[u], ares[u]);
-        issue_x(0);
-#pragma unroll
-        for (int u = 0; u < SU; ++u) {
-            __syncthreads();
-            if (u + 1 < SU) issue_x(u + 1);
-            compute(u, wres[u], ares[u]);
-        }
-    } else {
-        u32x2 wq_n[RT];
-        float am_n[RT];
-        load_w(0, wq_n, am_n);
-        issue_x(0);
-        for (int s = 0; s < steps; ++s) {
-            __syncthreads();  // step s has landed (every wave waits for its own DMAs first); slot (s+1)&1 is free again
-            u32x2 wq[RT];
-            float am[RT];
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt) wq[rt] = wq_n[rt], am[rt] = am_n[rt];
-            if (s + 1 < steps) {  // uniform
-                issue_x(s + 1);
-                load_w(s + 1, wq_n, am_n);
-            }
-            compute(s, wq, am);
-        }
-    }
-    __syncthreads();  // every wave is done with the ring before the partials overwrite it
-    wide_epilogue<DT, NT, RT, WR>(s_raw, acc, bias, residual, out, B, M, row0, mode);
-}
-
-// ---- tall weights: every global stream by LDS-DMA, the weight stream seven steps deep --------------------------------------
+// ---- tall weights: 32*RT rows per workgroup, the weight stream seven steps deep ---------------------------------------------------
 // Fragment-shaped weight loads (8 bytes per lane from 16 different rows) keep the texture path busy for four cache-line lookups
-// per quad, and a load issued inside the step loop can only be one step deep (above).  Here WR = 2, WK = 4 and
+// per quad, and a load issued inside the step loop can only be one step deep: the LDS-DMA of x shares the in-order load counter, and
+// waiting for x retires every older load with it.  Here WR = 2, WK = 4 and
 //   * per step the workgroup's 32*RT rows x 128 B of weight (the four K slices' blocks are one full line per row) and their
 //     32*RT x 4 scales are fetched by waves 4..7 with LDS-DMA in full lines into a ring of kDw steps; these waves issue nothing
 //     else, so a counted s_waitcnt vmcnt leaves kDw - 2 steps of weight in flight across every barrier;
@@ -377,53 +243,131 @@ __global__ __launch_bounds__(512) void gemm16_wide_ring_kernel(const uint16_t *_
     wide_epilogue<DT, NT, RT, WR>(s_raw, acc, bias, residual, out, B, M, row0, mode);
 }
 
-std::atomic<int> g_wide_cfg{-1};  // -1 heuristic; 0 = never (16-row launches); 1..5 = (RT, WR) in {(1,1), (2,1), (2,2), (2,4), (1,2)}; +8 = streaming loop
+// ---- short weights: 16 rows per workgroup, K split 8 ways, two DEDICATED loader waves ---------------------------------------------
+// With 8 K slices every compute wave already fetches its own x slice; the weight stream gets two extra waves (8 and 9) that do
+// nothing else: per step 16 rows x 256 B of weight (the eight slices' blocks: two full lines per row; 2 DMAs per loader wave) and
+// 16 x 8 scales (1 DMA of 4 bytes per lane each) into a ring of DW steps, DW - 2 of them in flight across every barrier.
+// Weight image: [row][256 B] with 16-byte piece ^ row on the DMA source and on the ds_read_b64 (conflict-free).
+template <int DT, int NT>
+__global__ __launch_bounds__(640) void gemm16_wide_ring8_kernel(const uint16_t *__restrict__ x, const uint8_t *__restrict__ W,
+                                                                const float *__restrict__ absmax, const uint16_t *__restrict__ bias,
+                                                                const uint16_t *residual, uint16_t *out, int B, int M, int K, int mode) {
+    constexpr int WK = 8, DW = NT == 4 ? 6 : 8;  // NT = 4: the x ring alone is 128 KB
+    constexpr int kSlot = NT * 2048, kXRing = 2 * WK * kSlot;
+    constexpr int kWSlot = 16 * 256, kSSlot = 16 * 32;
+    constexpr int kPart = WK * NT * 1024;
+    constexpr int kXBytes = kXRing > kPart ? kXRing : kPart;
+    constexpr int kPerStep = 3;
+    __shared__ __attribute__((aligned(1024))) uint8_t s_raw[kXBytes + DW * (kWSlot + kSSlot)];
+    uint8_t *s_w = s_raw + kXBytes, *s_s = s_w + DW * kWSlot;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wk = wave & 7;
+    const int i = lane & 15, kb = lane >> 4;
+    const int row0 = blockIdx.x * 16;
+    const int nblk = K >> 6, steps = nblk / WK;
+    const bool loader = wave >= 8;  // wave-uniform
+    const int v = wave & 1;         // loader index
 
-template <int DT, int NT, int RT, int WR, int SU>
-int launch_wide(const void *x, const uint8_t *W, const float *absmax, const void *bias, const void *residual, void *out, int B, int M,
-                int K, int mode, hipStream_t stream) {
-    const unsigned blocks = (unsigned)((M + 16 * RT * WR - 1) / (16 * RT * WR));
-    hipLaunchKernelGGL((gemm16_wide_kernel<DT, NT, RT, WR, SU>), dim3(blocks), dim3(512), 0, stream,
-                       reinterpret_cast<const uint16_t *>(x), W, absmax, reinterpret_cast<const uint16_t *>(bias),
-                       reinterpret_cast<const uint16_t *>(residual), reinterpret_cast<uint16_t *>(out), B, M, K, mode);
-    return FP4_OK;
+    uint32_t xoff[2 * NT];
+#pragma unroll
+    for (int d = 0; d < 2 * NT; ++d) {
+        const int n = 8 * d + (lane >> 3), sl = lane & 7;
+        const int nn = n < B ? n : B - 1;
+        xoff[d] = (uint32_t)nn * (uint32_t)K * 2u + (uint32_t)((sl ^ ((n >> 1) & 7)) * 16);
+    }
+    const uint8_t *xb = reinterpret_cast<const uint8_t *>(x);
+    // loader v, DMA d -> rows 4*(2v + d) .. +3; lane -> (row, 16-byte piece of the row's 256 B)
+    const uint8_t *wsrc[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+        const int rl = 4 * (2 * v + d) + (lane >> 4), sl = lane & 15;
+        const int r = row0 + rl;
+        const int64_t row = r < M ? r : M - 1;
+        wsrc[d] = W + row * (int64_t)(K >> 1) + ((sl ^ rl) * 16);
+    }
+    // scales: loader v -> rows 8v .. 8v+7; lane -> (row, K slice)
+    const int srl = 8 * v + (lane >> 3);
+    const float *ssrc = absmax + (int64_t)(row0 + srl < M ? row0 + srl : M - 1) * nblk + (lane & 7);
+
+    const int xrd0 = i * 128 + (((2 * kb) ^ (i >> 1)) * 16), xrd1 = i * 128 + (((2 * kb + 1) ^ (i >> 1)) * 16);
+    const int wrd = i * 256 + (((2 * wk + (kb >> 1)) ^ i) * 16) + (kb & 1) * 8;
+    const int srd = i * 32 + wk * 4;
+
+    f32x4 acc[1][NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[0][nt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+    auto issue_x = [&](int s) {  // compute wave: its own K slice
+        uint8_t *slot = s_raw + ((s & 1) * WK + wk) * kSlot;
+#pragma unroll
+        for (int d = 0; d < 2 * NT; ++d) lds_dma16(xb + xoff[d] + (uint32_t)(s * WK + wk) * 128u, slot + d * 1024);
+    };
+    auto issue_w = [&](int s) {  // loader wave
+        const int ring = s % DW;
+#pragma unroll
+        for (int d = 0; d < 2; ++d) lds_dma16(wsrc[d] + s * 256, s_w + ring * kWSlot + (2 * v + d) * 1024);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ssrc + s * 8),
+                                         (__attribute__((address_space(3))) void *)(s_s + ring * kSSlot + v * 256), 4, 0, 0);
+    };
+    if (loader) {
+        for (int s = 0; s < DW - 1 && s < steps; ++s) issue_w(s);
+    } else {
+        issue_x(0);
+    }
+    for (int s = 0; s < steps; ++s) {
+        if (loader && s + DW - 2 < steps)
+            wait_vmcnt<(DW - 2) * kPerStep>();
+        else
+            wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (loader) {
+            if (s + DW - 1 < steps) issue_w(s + DW - 1);
+            continue;  // loader waves take no part in the arithmetic
+        }
+        if (s + 1 < steps) issue_x(s + 1);
+        const uint8_t *xs = s_raw + ((s & 1) * WK + wk) * kSlot;
+        const u32x2 wq = *reinterpret_cast<const u32x2 *>(s_w + (s % DW) * kWSlot + wrd);
+        const float am = *reinterpret_cast<const float *>(s_s + (s % DW) * kSSlot + srd);
+        f32x4 tile[NT];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const u32x4 wf = decode8_natural<DT>(t == 0 ? wq.x : wq.y);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const u32x4 xf = *reinterpret_cast<const u32x4 *>(xs + nt * 2048 + (t == 0 ? xrd0 : xrd1));
+                tile[nt] = mfma_xw<DT>(xf, wf, t == 0 ? f32x4{0.0f, 0.0f, 0.0f, 0.0f} : tile[nt]);
+            }
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            acc[0][nt].x = __builtin_fmaf(tile[nt].x, am, acc[0][nt].x);
+            acc[0][nt].y = __builtin_fmaf(tile[nt].y, am, acc[0][nt].y);
+            acc[0][nt].z = __builtin_fmaf(tile[nt].z, am, acc[0][nt].z);
+            acc[0][nt].w = __builtin_fmaf(tile[nt].w, am, acc[0][nt].w);
+        }
+    }
+    __syncthreads();
+    wide_epilogue<DT, NT, 1, 1, 640>(s_raw, acc, bias, residual, out, B, M, row0, mode);
 }
+
+std::atomic<int> g_wide_cfg{-1};  // -1 heuristic; 0 = never (16-row launches); 1 / 2 / 3 = 16 / 32 / 64 rows per workgroup
 
 template <int DT, int NT>
 int dispatch_wide_cfg(int cfg, const void *x, const uint8_t *W, const float *absmax, const void *bias, const void *residual, void *out,
                       int B, int M, int K, int mode, hipStream_t stream) {
-    const int nblk = K >> 6;
-    const bool resident = (cfg & 8) == 0;  // bit 3 of the sweep hook forces the streaming loop
-#define FP4_WIDE(RT_, WR_, SU_) return launch_wide<DT, NT, RT_, WR_, SU_>(x, W, absmax, bias, residual, out, B, M, K, mode, stream)
-    switch (cfg & 7) {
-        case 1:
-            if (resident && nblk == 64) FP4_WIDE(1, 1, 8);
-            FP4_WIDE(1, 1, 0);
-        case 2:
-            FP4_WIDE(2, 1, 0);
-        case 3:
-            FP4_WIDE(2, 2, 0);
-        case 5:
-            FP4_WIDE(1, 2, 0);
-        case 6:
-        case 7: {
-            constexpr int RTc = 2;
-            (void)RTc;
-            const unsigned rows = (cfg & 7) == 6 ? 64u : 32u;
-            const unsigned blocks = ((unsigned)M + rows - 1) / rows;
-            if ((cfg & 7) == 6)
-                hipLaunchKernelGGL((gemm16_wide_ring_kernel<DT, NT, 2>), dim3(blocks), dim3(512), 0, stream,
-                                   reinterpret_cast<const uint16_t *>(x), W, absmax, reinterpret_cast<const uint16_t *>(bias),
-                                   reinterpret_cast<const uint16_t *>(residual), reinterpret_cast<uint16_t *>(out), B, M, K, mode);
-            else
-                hipLaunchKernelGGL((gemm16_wide_ring_kernel<DT, NT, 1>), dim3(blocks), dim3(512), 0, stream,
-                                   reinterpret_cast<const uint16_t *>(x), W, absmax, reinterpret_cast<const uint16_t *>(bias),
-                                   reinterpret_cast<const uint16_t *>(residual), reinterpret_cast<uint16_t *>(out), B, M, K, mode);
-            return FP4_OK;
-        }
-        default: FP4_WIDE(2, 4, 0);
-    }
-#undef FP4_WIDE
+    const unsigned rows = cfg == 1 ? 16u : (cfg == 2 ? 32u : 64u);
+    const dim3 grid(((unsigned)M + rows - 1) / rows);
+#define FP4_WIDE_ARGS reinterpret_cast<const uint16_t *>(x), W, absmax, reinterpret_cast<const uint16_t *>(bias), \
+                      reinterpret_cast<const uint16_t *>(residual), reinterpret_cast<uint16_t *>(out), B, M, K, mode
+    if (cfg == 1)
+        hipLaunchKernelGGL((gemm16_wide_ring8_kernel<DT, NT>), grid, dim3(640), 0, stream, FP4_WIDE_ARGS);
+    else if (cfg == 2)
+        hipLaunchKernelGGL((gemm16_wide_ring_kernel<DT, NT, 1>), grid, dim3(512), 0, stream, FP4_WIDE_ARGS);
+    else
+        hipLaunchKernelGGL((gemm16_wide_ring_kernel<DT, NT, 2>), grid, dim3(512), 0, stream, FP4_WIDE_ARGS);
+#undef FP4_WIDE_ARGS
+    return FP4_OK;
 }
 
 template <int DT>
@@ -437,7 +381,7 @@ int dispatch_wide(int cfg, const void *x, const uint8_t *W, const float *absmax,
 
 }  // namespace
 
-void set_wide_variant(int v) { g_wide_cfg = v < 0 ? -1 : (v & 15); }
+void set_wide_variant(int v) { g_wide_cfg = v < 0 ? -1 : (v > 3 ? 3 : v); }
 
 // 17..64 activation rows, 16-bit dtype, blocksize 64, K % 512 == 0, 16-byte aligned operands.  Returns FP4_OK after the launch, or
 // -1 when the shape is not covered / the path is switched off (the caller then streams the weight once per 16 rows).
@@ -447,19 +391,10 @@ int gemm_wide_launch(int dtype, const void *x, const uint8_t *W, const float *ab
     if (cfg == 0 || B <= 16 || B > 64 || (K % 512) != 0 || M < 1) return -1;
     if ((uint64_t)B * (uint64_t)K * 2u >= (uint64_t(1) << 32)) return -1;  // 32-bit x offsets
     if (cfg < 0) {
-        // Measured (profiles/r02_wide_batch_17_to_128_rows.txt, MI355X): tall weights - 64 rows per workgroup on the all-DMA ring
-        // kernel once that fills three quarters of the chip, 32 rows from half of that; below, 16 rows per workgroup with the
-        // register-resident weight stream (K = 4096) - and there, for K != 4096 and at most 32 rows, two 16-row launches are
-        // still ahead (4096 x 14336 x 32 rows: 34.7 vs 37.3 us).
+        // Measured (profiles/r02_wide_batch_17_to_128_rows.txt, MI355X): 64 rows per workgroup once that fills three quarters of the
+        // chip, 32 rows from half of that, below it 16 rows with two loader waves - all three with every stream by LDS-DMA.
         const int cus = device_cu_count();
-        if (M >= 48 * cus)
-            cfg = 6;
-        else if (M >= 24 * cus)
-            cfg = 7;
-        else if (K == 4096 || B > 32)
-            cfg = 1;
-        else
-            return -1;
+        cfg = M >= 48 * cus ? 3 : (M >= 24 * cus ? 2 : 1);
     }
     return dtype == FP4_DTYPE_F16 ? dispatch_wide<FP4_DTYPE_F16>(cfg, x, W, absmax, bias, residual, out, B, M, K, mode, stream)
                                   : dispatch_wide<FP4_DTYPE_BF16>(cfg, x, W, absmax, bias, residual, out, B, M, K, mode, stream);
