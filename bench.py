@@ -492,16 +492,24 @@ def main():
                 extra[f"dequant_{name}_us"] = round(us, 3)
                 extra[f"dequant_{name}_gbps"] = round(dequant_bytes(M, K, BLOCKSIZE, o32[0].element_size()) / us / 1e3, 1)
                 del o32, rp
-            # the rows SURVEY 8(f) marks "next", HBM-cold like the headline: fused small batch (2..16 activation rows,
-            # same weight traffic as the GEMV) and the quantiser (reads the bf16 weights the dequant above just wrote)
+            # the rows SURVEY 8(f) marks "next", HBM-cold like the headline: fused small batch (2..16 activation rows on one
+            # matrix-core tile, 32 / 64 rows in one pass over the weight, 128 rows as two such passes: same weight traffic as the
+            # GEMV per pass) and the quantiser (reads the bf16 weights the dequant above just wrote)
             sb = {}
-            for b in (2, 4, 8, 16):
+            for b in (2, 4, 8, 16, 32, 64, 128):
                 xb = torch.randn(b, K, device=dev).to(torch.bfloat16)
                 yb = torch.empty(b, M, dtype=torch.bfloat16, device=dev)
                 rp = capture(lambda: [lib.gemm_small(xb, packed[i], absmax[i], yb, b, M, K) for i in range(R)])
                 sb[str(b)] = round(time_replays(rp, 5, R)[0], 3)
                 del rp
             extra["small_batch_us_by_rows"] = sb
+            # the reference's path for the same rows: dequantise to bf16, then the dense GEMM (hipBLASLt)
+            x64 = torch.randn(64, K, device=dev).to(torch.bfloat16)
+            def dq_gemm64():
+                for i in range(R):
+                    lib.dequant(packed[i], absmax[i], outs[i], n)
+                    torch.nn.functional.linear(x64, outs[i].view(M, K))
+            extra["dequant_plus_hipblaslt_gemm_64_rows_us"] = round(time_replays(capture(dq_gemm64), 5, R)[0], 3)
             qp, qa = torch.empty(n // 2, dtype=torch.uint8, device=dev), torch.empty(n // BLOCKSIZE, dtype=torch.float32, device=dev)
             rp = capture(lambda: [lib.quantize(outs[i % len(outs)], qp, qa, n) for i in range(R)])
             us = time_replays(rp, 5, R)[0]
