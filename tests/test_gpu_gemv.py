@@ -235,10 +235,13 @@ def test_partial_f32_output_and_k_split_sum(dtype):
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("kernel", [0, 1 | (1 << 4), 1 | (2 << 4), 1 | (1 << 4) | (1 << 8), 1 | (2 << 4) | (1 << 8), 1 | (1 << 4) | (2 << 14)])  # VALU kernel; matrix-core kernel: 1 / 2 row tiles, LDS-staged / direct weight loads, 8 blocks per pass wherever they divide K
 @pytest.mark.parametrize("B", [1, 2, 3, 4, 5, 8, 9, 13, 16])
-@pytest.mark.parametrize("M,K", [(4096, 4096), (1024, 4096), (2048, 768), (66, 2048), (257, 1024), (300, 8192), (40, 14336), (33, 512)])
+@pytest.mark.parametrize("M,K", [(4096, 4096), (1024, 4096), (2048, 768), (66, 2048), (257, 1024), (300, 8192), (40, 14336), (33, 512),
+                                 (130, 11008), (48, 1472)])
 def test_small_batch_fused_gemm(dtype, kernel, B, M, K):
     """fp4_hip_gemm_small: 1..16 activation rows against the float64 product, same bar as the GEMV (one rounding);
-    both kernels, every shape class (VALU band splits, MFMA blocks-per-wave 1/2/4/8, ragged M, B not a power of two)."""
+    both kernels, every shape class (VALU band splits, MFMA blocks-per-wave 1/2/4/8, ragged M, B not a power of two).  K % 512 != 0
+    beyond the VALU kernel's reach (11008 = Llama-2-7B's down projection, 1472 = 23 blocks) lands on the one-pass kernels of
+    gemm_wide_fp4.hip with one column tile and a ragged last step."""
     packed, am, _ = make_case(M, K, seed=B * 1000 + M)
     rng = np.random.default_rng(B)
     x = rng.standard_normal((B, K)).astype(np.float32)
@@ -249,10 +252,7 @@ def test_small_batch_fused_gemm(dtype, kernel, B, M, K):
     mfma_ok = K % 512 == 0
     hipabi.set_variant("gemm_small", kernel)
     try:
-        if not (valu_ok or mfma_ok):
-            rc = hipabi.gemm_small(x_t, to_dev(packed), to_dev(am), M, K, 64, expect_ok=False)
-            assert rc == hipabi.ERR_UNSUPPORTED and "dequant + GEMM" in hipabi.last_error()
-            return
+        assert valu_ok or mfma_ok or K % 64 == 0
         y = hipabi.gemm_small(x_t, to_dev(packed), to_dev(am), M, K, 64, bias=b_t)
     finally:
         hipabi.set_variant("gemm_small", -1)
@@ -328,7 +328,7 @@ def test_small_batch_beyond_16_rows_chunked_path(dtype, B, M, K):
         assert (err <= HALF_ULP[dtype] * 1.01 * np.abs(exact) + 1e-5 * (wabs @ np.abs(xv)) + 1e-30).all(), (b, err.max())
 
 
-WIDE_SHAPES = [(4096, 4096), (1024, 4096), (300, 8192), (66, 2048), (33, 512), (130, 14336), (257, 1024)]
+WIDE_SHAPES = [(4096, 4096), (1024, 4096), (300, 8192), (66, 2048), (33, 512), (130, 14336), (257, 1024), (130, 11008), (66, 768), (40, 1472)]
 _WIDE_CASES = {}
 
 
@@ -395,6 +395,10 @@ def test_wide_batch_default_dispatch_and_row_limits(dtype):
     assert torch.equal(y100[50:], hipabi.gemm_small(x_t[50:100].contiguous(), P, A, M, K, 64))
     too_many = torch.zeros(129, K, dtype=dtype, device=dev())
     assert hipabi.gemm_small(too_many, P, A, M, K, 64, expect_ok=False) == hipabi.ERR_INVALID
+    # what stays outside every small-batch kernel: more than 8 rows on a blocksize other than 64 -> the caller's dequant + GEMM
+    A128 = torch.ones(M * K // 128, device=dev())
+    rc = hipabi.gemm_small(x_t[:12].contiguous(), P, A128, M, K, 128, expect_ok=False)
+    assert rc == hipabi.ERR_UNSUPPORTED and "dequant + GEMM" in hipabi.last_error()
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

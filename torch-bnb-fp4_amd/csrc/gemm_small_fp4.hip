@@ -716,7 +716,7 @@ void set_small_variant(int v) {
 
 namespace fp4 {
 int gemm_wide_launch(int dtype, const void *x, const uint8_t *W, const float *absmax, const void *bias, const void *residual, void *out,
-                     int B, int M, int K, int mode, hipStream_t stream);  // gemm_wide_fp4.hip
+                     int B, int M, int K, int mode, bool any_rows, hipStream_t stream);  // gemm_wide_fp4.hip
 namespace {
 int gemm_small_entry(const void *x, const uint8_t *packed, const float *absmax, const void *bias, const void *residual, void *out,
                      int64_t B, int64_t M, int64_t K, int blocksize, int dtype, int mode, void *stream) {
@@ -740,7 +740,7 @@ int gemm_small_entry(const void *x, const uint8_t *packed, const float *absmax, 
         const uintptr_t al = reinterpret_cast<uintptr_t>(packed) | reinterpret_cast<uintptr_t>(x);
         if (B <= 64 && M > 0 && x && packed && absmax && out && blocksize == 64 && (al & 15u) == 0 && M <= (int64_t(1) << 30) &&
             K <= (int64_t(1) << 24) &&
-            gemm_wide_launch(dtype, x, packed, absmax, bias, residual, out, (int)B, (int)M, (int)K, mode, static_cast<hipStream_t>(stream)) == FP4_OK)
+            gemm_wide_launch(dtype, x, packed, absmax, bias, residual, out, (int)B, (int)M, (int)K, mode, false, static_cast<hipStream_t>(stream)) == FP4_OK)
             return check_launch("fp4_hip_gemm_small");
         const int64_t unit = B > 64 ? 64 : 16;
         const int64_t chunks = (B + unit - 1) / unit, per = (B + chunks - 1) / chunks;
@@ -779,6 +779,10 @@ int gemm_small_entry(const void *x, const uint8_t *packed, const float *absmax, 
     if (rc == -1 && mfma_ok)
         rc = dtype == FP4_DTYPE_F16 ? dispatch_mfma<FP4_DTYPE_F16>(x, packed, absmax, bias, residual, out, (int)B, (int)M, (int)K, mode, s)
                                     : dispatch_mfma<FP4_DTYPE_BF16>(x, packed, absmax, bias, residual, out, (int)B, (int)M, (int)K, mode, s);
+    // K % 512 != 0 beyond the VALU kernel's reach (e.g. Llama-2-7B's down projection, K = 11008): the one-pass kernels of
+    // gemm_wide_fp4.hip take any K % 64 == 0 and 1..64 rows
+    if (rc == -1 && ok && blocksize == 64 && (K % 64) == 0)
+        rc = gemm_wide_launch(dtype, x, packed, absmax, bias, residual, out, (int)B, (int)M, (int)K, mode, true, s);
     if (rc == -1) {
         set_error("fp4_hip_gemm_small: shape B=%lld M=%lld K=%lld blocksize=%d dtype=%d is not covered; use dequant + GEMM",
                   (long long)B, (long long)M, (long long)K, blocksize, dtype);

@@ -128,7 +128,7 @@ __global__ __launch_bounds__(512) void gemm16_wide_ring_kernel(const uint16_t *_
     const int wr = wave % WR, wk = wave / WR;
     const int i = lane & 15, kb = lane >> 4;
     const int row0 = blockIdx.x * kRows;
-    const int nblk = K >> 6, steps = nblk / WK;
+    const int nblk = K >> 6, steps = (nblk + WK - 1) / WK;  // K % 256 != 0: ragged last step, handled as in the 16-row kernel below
     const bool loader = wave >= 4;  // wave-uniform
 
     // x: wave w < 4 fills K slice w: DMA d -> columns 8d .. 8d+7
@@ -142,18 +142,20 @@ __global__ __launch_bounds__(512) void gemm16_wide_ring_kernel(const uint16_t *_
     const uint8_t *xb = reinterpret_cast<const uint8_t *>(x);
     // weights: loader wave v = wave - 4, DMA d -> rows 8*(v*kWDma + d) .. +7 of the workgroup; lane -> (row, 16-byte piece)
     const uint8_t *wsrc[kWDma];
+    int wpiece[kWDma];
 #pragma unroll
     for (int d = 0; d < kWDma; ++d) {
         const int rl = 8 * (((wave - 4) & 3) * kWDma + d) + (lane >> 3), sl = lane & 7;
         const int r = row0 + rl;
         const int64_t row = r < M ? r : M - 1;
-        wsrc[d] = W + row * (int64_t)(K >> 1) + ((sl ^ ((rl >> 1) & 7)) * 16);
+        wpiece[d] = sl ^ ((rl >> 1) & 7);
+        wsrc[d] = W + row * (int64_t)(K >> 1);
     }
     // scales: lane -> (row, K slice); RT = 2: 16 rows per loader wave, RT = 1: 8 rows (lanes 0..31)
     constexpr int kSRows = kRows / 4;
     const int srl = ((wave - 4) & 3) * kSRows + (lane >> 2);
     const int srow = row0 + srl;
-    const float *ssrc = absmax + (int64_t)(srow < M ? srow : M - 1) * nblk + (lane & 3);
+    const float *ssrc = absmax + (int64_t)(srow < M ? srow : M - 1) * nblk;
     const bool slane = (lane >> 2) < kSRows;
 
     // fragment reads
@@ -173,17 +175,19 @@ __global__ __launch_bounds__(512) void gemm16_wide_ring_kernel(const uint16_t *_
         for (int nt = 0; nt < NT; ++nt) acc[rt][nt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 
     auto issue_x = [&](int s) {  // waves 0..3
+        if (s * WK + wave >= nblk) return;  // wave-uniform (ragged last step)
         uint8_t *slot = s_raw + ((s & 1) * WK + wave) * kSlot;
 #pragma unroll
         for (int d = 0; d < 2 * NT; ++d) lds_dma16(xb + xoff[d] + (uint32_t)(s * WK + wave) * 128u, slot + d * 1024);
     };
     auto issue_w = [&](int s) {  // waves 4..7
-        const int ring = s % kDw;
+        const int ring = s % kDw, left = nblk - s * WK;
 #pragma unroll
         for (int d = 0; d < kWDma; ++d)
-            lds_dma16(wsrc[d] + s * 128, s_w + ring * kWSlot + (((wave - 4) & 3) * kWDma + d) * 1024);
+            lds_dma16(wsrc[d] + s * 128 + ((wpiece[d] >> 1) < left ? wpiece[d] * 16 : 0),
+                      s_w + ring * kWSlot + (((wave - 4) & 3) * kWDma + d) * 1024);
         if (slane)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ssrc + s * 4),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ssrc + s * 4 + ((lane & 3) < left ? (lane & 3) : 0)),
                                              (__attribute__((address_space(3))) void *)(s_s + ring * kSSlot + ((wave - 4) & 3) * kSRows * 16),
                                              4, 0, 0);
     };
@@ -205,6 +209,7 @@ __global__ __launch_bounds__(512) void gemm16_wide_ring_kernel(const uint16_t *_
         } else if (s + 1 < steps) {
             issue_x(s + 1);
         }
+        if (s * WK + wk >= nblk) continue;  // wave-uniform (ragged last step): no block for this K slice
         const uint8_t *xs = s_raw + ((s & 1) * WK + wk) * kSlot;
         const uint8_t *ws = s_w + (s % kDw) * kWSlot;
         const uint8_t *ss = s_s + (s % kDw) * kSSlot;
@@ -264,7 +269,9 @@ __global__ __launch_bounds__(640) void gemm16_wide_ring8_kernel(const uint16_t *
     const int wk = wave & 7;
     const int i = lane & 15, kb = lane >> 4;
     const int row0 = blockIdx.x * 16;
-    const int nblk = K >> 6, steps = nblk / WK;
+    // K % 512 != 0: the last step is ragged - K slices past the row's end skip their DMA and their arithmetic, and the loader
+    // lanes whose bytes would lie past the row's end re-read the step's first piece instead (never used)
+    const int nblk = K >> 6, steps = (nblk + WK - 1) / WK;
     const bool loader = wave >= 8;  // wave-uniform
     const int v = wave & 1;         // loader index
 
@@ -278,16 +285,18 @@ __global__ __launch_bounds__(640) void gemm16_wide_ring8_kernel(const uint16_t *
     const uint8_t *xb = reinterpret_cast<const uint8_t *>(x);
     // loader v, DMA d -> rows 4*(2v + d) .. +3; lane -> (row, 16-byte piece of the row's 256 B)
     const uint8_t *wsrc[2];
+    int wpiece[2];
 #pragma unroll
     for (int d = 0; d < 2; ++d) {
         const int rl = 4 * (2 * v + d) + (lane >> 4), sl = lane & 15;
         const int r = row0 + rl;
         const int64_t row = r < M ? r : M - 1;
-        wsrc[d] = W + row * (int64_t)(K >> 1) + ((sl ^ rl) * 16);
+        wpiece[d] = sl ^ rl;
+        wsrc[d] = W + row * (int64_t)(K >> 1);
     }
     // scales: loader v -> rows 8v .. 8v+7; lane -> (row, K slice)
     const int srl = 8 * v + (lane >> 3);
-    const float *ssrc = absmax + (int64_t)(row0 + srl < M ? row0 + srl : M - 1) * nblk + (lane & 7);
+    const float *ssrc = absmax + (int64_t)(row0 + srl < M ? row0 + srl : M - 1) * nblk;
 
     const int xrd0 = i * 128 + (((2 * kb) ^ (i >> 1)) * 16), xrd1 = i * 128 + (((2 * kb + 1) ^ (i >> 1)) * 16);
     const int wrd = i * 256 + (((2 * wk + (kb >> 1)) ^ i) * 16) + (kb & 1) * 8;
@@ -298,15 +307,17 @@ __global__ __launch_bounds__(640) void gemm16_wide_ring8_kernel(const uint16_t *
     for (int nt = 0; nt < NT; ++nt) acc[0][nt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 
     auto issue_x = [&](int s) {  // compute wave: its own K slice
+        if (s * WK + wk >= nblk) return;  // wave-uniform: no such block (ragged last step)
         uint8_t *slot = s_raw + ((s & 1) * WK + wk) * kSlot;
 #pragma unroll
         for (int d = 0; d < 2 * NT; ++d) lds_dma16(xb + xoff[d] + (uint32_t)(s * WK + wk) * 128u, slot + d * 1024);
     };
     auto issue_w = [&](int s) {  // loader wave
-        const int ring = s % DW;
+        const int ring = s % DW, left = nblk - s * WK;  // blocks of this step that exist (>= 1)
 #pragma unroll
-        for (int d = 0; d < 2; ++d) lds_dma16(wsrc[d] + s * 256, s_w + ring * kWSlot + (2 * v + d) * 1024);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ssrc + s * 8),
+        for (int d = 0; d < 2; ++d)
+            lds_dma16(wsrc[d] + s * 256 + ((wpiece[d] >> 1) < left ? wpiece[d] * 16 : 0), s_w + ring * kWSlot + (2 * v + d) * 1024);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ssrc + s * 8 + ((lane & 7) < left ? (lane & 7) : 0)),
                                          (__attribute__((address_space(3))) void *)(s_s + ring * kSSlot + v * 256), 4, 0, 0);
     };
     if (loader) {
@@ -326,6 +337,7 @@ __global__ __launch_bounds__(640) void gemm16_wide_ring8_kernel(const uint16_t *
             continue;  // loader waves take no part in the arithmetic
         }
         if (s + 1 < steps) issue_x(s + 1);
+        if (s * WK + wk >= nblk) continue;  // wave-uniform (ragged last step)
         const uint8_t *xs = s_raw + ((s & 1) * WK + wk) * kSlot;
         const u32x2 wq = *reinterpret_cast<const u32x2 *>(s_w + (s % DW) * kWSlot + wrd);
         const float am = *reinterpret_cast<const float *>(s_s + (s % DW) * kSSlot + srd);
@@ -374,6 +386,7 @@ template <int DT>
 int dispatch_wide(int cfg, const void *x, const uint8_t *W, const float *absmax, const void *bias, const void *residual, void *out, int B,
                   int M, int K, int mode, hipStream_t stream) {
     const int nt = (B + 15) / 16;
+    if (nt == 1) return dispatch_wide_cfg<DT, 1>(cfg, x, W, absmax, bias, residual, out, B, M, K, mode, stream);
     if (nt == 2) return dispatch_wide_cfg<DT, 2>(cfg, x, W, absmax, bias, residual, out, B, M, K, mode, stream);
     if (nt == 3) return dispatch_wide_cfg<DT, 3>(cfg, x, W, absmax, bias, residual, out, B, M, K, mode, stream);
     return dispatch_wide_cfg<DT, 4>(cfg, x, W, absmax, bias, residual, out, B, M, K, mode, stream);
@@ -383,12 +396,13 @@ int dispatch_wide(int cfg, const void *x, const uint8_t *W, const float *absmax,
 
 void set_wide_variant(int v) { g_wide_cfg = v < 0 ? -1 : (v > 3 ? 3 : v); }
 
-// 17..64 activation rows, 16-bit dtype, blocksize 64, K % 512 == 0, 16-byte aligned operands.  Returns FP4_OK after the launch, or
-// -1 when the shape is not covered / the path is switched off (the caller then streams the weight once per 16 rows).
+// 17..64 activation rows (any_rows: 1..64 - the caller's other kernels do not cover the shape), 16-bit dtype, blocksize 64,
+// K % 64 == 0, 16-byte aligned operands.  Returns FP4_OK after the launch, or -1 when the shape is not covered / the path is switched
+// off (the caller then streams the weight once per 16 rows).
 int gemm_wide_launch(int dtype, const void *x, const uint8_t *W, const float *absmax, const void *bias, const void *residual, void *out,
-                     int B, int M, int K, int mode, hipStream_t stream) {
+                     int B, int M, int K, int mode, bool any_rows, hipStream_t stream) {
     int cfg = g_wide_cfg.load(std::memory_order_relaxed);
-    if (cfg == 0 || B <= 16 || B > 64 || (K % 512) != 0 || M < 1) return -1;
+    if (cfg == 0 || B < 1 || (B <= 16 && !any_rows) || B > 64 || (K % 64) != 0 || M < 1) return -1;
     if ((uint64_t)B * (uint64_t)K * 2u >= (uint64_t(1) << 32)) return -1;  // 32-bit x offsets
     if (cfg < 0) {
         // Measured (profiles/r02_wide_batch_17_to_128_rows.txt, MI355X): 64 rows per workgroup once that fills three quarters of the
