@@ -118,7 +118,8 @@ FP4_HIP_API int fp4_hip_gemv_fused(const void *x, const uint8_t *packed, const f
  * writing and re-reading the M*K dequantised weight).  16-bit dtypes only.  Two kernels: a matrix-core one
  * (v_mfma_f32_16x16x32; blocksize 64, K % 512 == 0; any B <= 16) and a VALU one (B <= 8; K % 32 == 0, K <= 16384,
  * less for larger B; power-of-two blocksize >= 32 dividing K).  Returns FP4_ERR_UNSUPPORTED for shapes neither
- * covers, so the caller can fall back to dequant + GEMM.  17..64 rows (blocksize 64, K % 512 == 0): ONE pass over the
+ * covers, so the caller can fall back to dequant + GEMM.  17..64 rows (blocksize 64, K % 64 == 0; and 1..16 rows where
+ * K % 512 != 0 keeps the two kernels above out, e.g. K = 11008): ONE pass over the
  * weight on the matrix cores with 2..4 column tiles of x per decoded weight fragment (x staged through LDS by LDS-DMA);
  * where that kernel does not apply the rows are split evenly over ceil(B/16) launches, each streaming the weight once.
  * 65..128 rows: two even chunks of at most 64.  Measured against dequant + hipBLASLt GEMM on MI355X

@@ -138,7 +138,10 @@ def test_small_batch_opt_in(fake):
     ref = torch.nn.functional.linear(x.float(), wq, lin.bias.float())
     assert (y.float() - ref).abs().max() <= 6e-2 * max(1.0, ref.abs().max().item())
     fake.calls.clear()
-    qd.forward(torch.randn(9, 128).to(torch.bfloat16))  # > 8 rows: the reference path
+    qd.forward(torch.randn(9, 128).to(torch.bfloat16))  # blocksize 64, K % 64 == 0: fused up to 128 rows
+    assert fake.calls == ["gemm_small_fp4"]
+    fake.calls.clear()
+    qd.forward(torch.randn(129, 128).to(torch.bfloat16))  # more rows: the reference path
     assert fake.calls == ["qlinear_codebook_bias"]
     fake.calls.clear()
     qd.forward(torch.randn(1, 128).to(torch.bfloat16))  # single token is still the GEMV
@@ -175,27 +178,19 @@ def test_fused_layers_dispatch_and_fall_back(fake, monkeypatch):
     u64 = o.gemv_exact(x.float().numpy().reshape(-1), pu, au, M, K, 64)
     want = o.silu_mul_epilogue(g64, u64, "bfloat16")
     assert np.array_equal(y.float().numpy().reshape(-1), want)
-    # 2..128 rows (K % 512 == 0; up to 8 rows for other K, as here): the same epilogue on the small-batch kernels; more rows: the
-    # unfused sequence (de-interleaving the rows)
+    # 2..128 rows (blocksize 64, K % 64 == 0): the same epilogue on the small-batch kernels; more rows: the unfused sequence
+    # (de-interleaving the rows)
     fake.calls.clear()
     xb = torch.cat([x, x])
     yb = gu(xb)
     assert fake.calls == ["gemm_small_fp4_fused"] and yb.shape == (2, M)
     assert (yb[0].float() - y[0].float()).abs().max() <= 0.05 * max(1.0, y.float().abs().max().item())
-    fake.calls.clear()
-    y40 = gu(x.repeat(40, 1))
-    assert "gemm_small_fp4_fused" not in fake.calls and "gemv_fp4_fused" not in fake.calls and y40.shape == (40, M)
-    assert (y40[7].float() - y[0].float()).abs().max() <= 0.05 * max(1.0, y.float().abs().max().item())
-    # K % 512 == 0: up to 128 rows stay on the fused kernels, 129 do not
-    M5, K5 = 4, 512
-    rng5 = np.random.default_rng(3)
-    t5 = [tuple(torch.from_numpy(a) for a in o.quantize_fp4((rng5.standard_normal(M5 * K5) * 0.05).astype(np.float32), 64)) for _ in range(2)]
-    gu5 = fused.FusedFP4Linear.gate_up_from_packed(t5[0], t5[1], (M5, K5), 64)
-    x5 = torch.randn(1, K5).to(torch.bfloat16)
     for rows, want_fused in ((40, True), (128, True), (129, False)):
         fake.calls.clear()
-        assert gu5(x5.repeat(rows, 1)).shape == (rows, M5)
-        assert ("gemm_small_fp4_fused" in fake.calls) == want_fused, (rows, fake.calls)
+        yr = gu(x.repeat(rows, 1))
+        assert yr.shape == (rows, M) and ("gemm_small_fp4_fused" in fake.calls) == want_fused, (rows, fake.calls)
+        assert "gemv_fp4_fused" not in fake.calls
+        assert (yr[7].float() - y[0].float()).abs().max() <= 0.05 * max(1.0, y.float().abs().max().item())
     # plain layer: residual in the epilogue for one token, added separately for a batch
     dn = fused.FusedFP4Linear.from_packed(*tg, (M, K), 64)
     r = torch.randn(1, M).to(torch.bfloat16)

@@ -138,7 +138,7 @@ class FusedFP4Linear(nn.Module):
                 self._fused_ok = False  # shape outside the fused kernel's coverage: unfused sequence from now on
         rows = x.numel() // K if K else 0
         if (self._small_ok and 2 <= rows <= 128 and K == self.in_features and x.dtype == qd.o_type and x.dtype in (torch.float16, torch.bfloat16)
-                and ((qd.blocksize == 64 and K % 512 == 0) or (rows <= 8 and K % qd.blocksize == 0 and K % 32 == 0 and K <= 4096))):
+                and ((qd.blocksize == 64 and K % 64 == 0) or (rows <= 8 and K % qd.blocksize == 0 and K % 32 == 0 and K <= 4096))):
             try:  # batched decode: the same epilogues on the small-batch kernels
                 return ext.gemm_small_fp4_fused(x.contiguous(), qd._B_t, qd.absmax, qd.blocksize, qd._shape_list, qd.bias, residual,
                                                 self.epilogue)

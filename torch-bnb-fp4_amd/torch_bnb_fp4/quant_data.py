@@ -147,6 +147,6 @@ class QuantData:
         # everything that is not a 2-D / 3-D single token with K % blocksize == 0 (:593-594, :614-617)
         rows = total // K
         if (self.small_batch_fused and 2 <= rows <= 128 and A.dtype in (torch.float16, torch.bfloat16)
-                and ((self.blocksize == 64 and K % 512 == 0) or (rows <= 8 and K % self.blocksize == 0 and K % 32 == 0 and K <= 4096))):
+                and ((self.blocksize == 64 and K % 64 == 0) or (rows <= 8 and K % self.blocksize == 0 and K % 32 == 0 and K <= 4096))):
             return ext.gemm_small_fp4(A.contiguous(), self.A.t(), self.absmax, self.blocksize, self._shape_list, self.bias)
         return self.qlinear(A)
