@@ -56,7 +56,7 @@ int main(int argc, char **argv) {
         fp4::set_wide_variant(cfg);
         auto pass = [&]() {
             for (int i = 0; i < R; ++i)
-                if (fp4::gemm_wide_launch(FP4_DTYPE_BF16, x, packed[i], absmax[i], nullptr, nullptr, out, B, M, K, 0, s) != FP4_OK) exit(2);
+                if (fp4::gemm_wide_launch(FP4_DTYPE_BF16, x, packed[i], absmax[i], nullptr, nullptr, out, B, M, K, 0, true, s) != FP4_OK) exit(2);
         };
         pass();
         CK(hipStreamSynchronize(s));

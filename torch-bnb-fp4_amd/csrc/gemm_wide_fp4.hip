@@ -257,8 +257,10 @@ template <int DT, int NT>
 __global__ __launch_bounds__(640) void gemm16_wide_ring8_kernel(const uint16_t *__restrict__ x, const uint8_t *__restrict__ W,
                                                                 const float *__restrict__ absmax, const uint16_t *__restrict__ bias,
                                                                 const uint16_t *residual, uint16_t *out, int B, int M, int K, int mode) {
-    constexpr int WK = 8, DW = NT == 4 ? 6 : 8;  // NT = 4: the x ring alone is 128 KB
-    constexpr int kSlot = NT * 2048, kXRing = 2 * WK * kSlot;
+    // ring depths: x DX slots per K slice (DX - 2 steps of x stay in flight across a barrier), weight DW steps; LDS decides:
+    // NT = 1: 64 + 36 KB, NT = 2: 128 + 27 KB, NT = 3: 96 + 36 KB, NT = 4: 128 + 27 KB
+    constexpr int WK = 8, DX = NT <= 2 ? 4 : 2, DW = (NT == 4 || NT == 2) ? 6 : 8;
+    constexpr int kSlot = NT * 2048, kXRing = DX * WK * kSlot;
     constexpr int kWSlot = 16 * 256, kSSlot = 16 * 32;
     constexpr int kPart = WK * NT * 1024;
     constexpr int kXBytes = kXRing > kPart ? kXRing : kPart;
@@ -308,7 +310,7 @@ __global__ __launch_bounds__(640) void gemm16_wide_ring8_kernel(const uint16_t *
 
     auto issue_x = [&](int s) {  // compute wave: its own K slice
         if (s * WK + wk >= nblk) return;  // wave-uniform: no such block (ragged last step)
-        uint8_t *slot = s_raw + ((s & 1) * WK + wk) * kSlot;
+        uint8_t *slot = s_raw + ((s % DX) * WK + wk) * kSlot;
 #pragma unroll
         for (int d = 0; d < 2 * NT; ++d) lds_dma16(xb + xoff[d] + (uint32_t)(s * WK + wk) * 128u, slot + d * 1024);
     };
@@ -323,11 +325,14 @@ __global__ __launch_bounds__(640) void gemm16_wide_ring8_kernel(const uint16_t *
     if (loader) {
         for (int s = 0; s < DW - 1 && s < steps; ++s) issue_w(s);
     } else {
-        issue_x(0);
+        for (int s = 0; s < DX - 1 && s < steps; ++s) issue_x(s);
     }
     for (int s = 0; s < steps; ++s) {
+        // step s has landed; younger steps may stay in flight (not in the last steps, where a ragged step issues fewer DMAs)
         if (loader && s + DW - 2 < steps)
             wait_vmcnt<(DW - 2) * kPerStep>();
+        else if (!loader && DX > 2 && s + DX - 2 < steps - 1)
+            wait_vmcnt<(DX - 2) * 2 * NT>();
         else
             wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
@@ -336,9 +341,9 @@ __global__ __launch_bounds__(640) void gemm16_wide_ring8_kernel(const uint16_t *
             if (s + DW - 1 < steps) issue_w(s + DW - 1);
             continue;  // loader waves take no part in the arithmetic
         }
-        if (s + 1 < steps) issue_x(s + 1);
+        if (s + DX - 1 < steps) issue_x(s + DX - 1);  // into the slot step s - 1 used
         if (s * WK + wk >= nblk) continue;  // wave-uniform (ragged last step)
-        const uint8_t *xs = s_raw + ((s & 1) * WK + wk) * kSlot;
+        const uint8_t *xs = s_raw + ((s % DX) * WK + wk) * kSlot;
         const u32x2 wq = *reinterpret_cast<const u32x2 *>(s_w + (s % DW) * kWSlot + wrd);
         const float am = *reinterpret_cast<const float *>(s_s + (s % DW) * kSSlot + srd);
         f32x4 tile[NT];
