@@ -101,10 +101,9 @@ __device__ __forceinline__ void wide_epilogue(uint8_t *s_raw, const f32x4 (&acc)
 //   * per step the workgroup's 32*RT rows x 128 B of weight (the four K slices' blocks are one full line per row) and their
 //     32*RT x 4 scales are fetched by waves 4..7 with LDS-DMA in full lines into a ring of kDw steps; these waves issue nothing
 //     else, so a counted s_waitcnt vmcnt leaves kDw - 2 steps of weight in flight across every barrier;
-//   * the x image of step s + 1 is fetched by waves 0..3 (wave w: K slice w), whose counter holds nothing else: vmcnt(0);
+//   * the x images are fetched by waves 0..3 (wave w: K slice w) DX - 1 steps ahead, whose counter holds nothing else: counted too;
 //   * the barrier is the bare s_barrier (a __syncthreads() fence would drain every wave's counter);
 //   * weight image: [row][128 B] with 16-byte piece ^ (row >> 1 & 7), applied to the DMA's source and to the ds_read_b64.
-constexpr int kDw = 8;
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -116,7 +115,11 @@ __global__ __launch_bounds__(512) void gemm16_wide_ring_kernel(const uint16_t *_
                                                                const float *__restrict__ absmax, const uint16_t *__restrict__ bias,
                                                                const uint16_t *residual, uint16_t *out, int B, int M, int K, int mode) {
     constexpr int WR = 2, WK = 4, kTiles = WR * RT, kRows = 16 * kTiles;
-    constexpr int kSlot = NT * 2048, kXRing = 2 * WK * kSlot;
+    // ring depths (LDS decides): x DX slots per K slice, weight kDw steps.  A step of this kernel is long (up to 16 MFMAs per wave), so
+    // three to four steps of weight in flight cover the HBM latency; what is left of the LDS goes to x.
+    constexpr int DX = (RT == 2 && NT == 4) ? 3 : 4;
+    constexpr int kDw = RT == 2 ? (NT == 4 ? 4 : (NT == 3 ? 5 : 8)) : (NT == 4 ? 6 : 8);
+    constexpr int kSlot = NT * 2048, kXRing = DX * WK * kSlot;
     constexpr int kWSlot = kRows * 128, kSSlot = kRows * 16;
     constexpr int kPart = WK * kTiles * NT * 1024;
     constexpr int kXBytes = kXRing > kPart ? kXRing : kPart;
@@ -176,7 +179,7 @@ __global__ __launch_bounds__(512) void gemm16_wide_ring_kernel(const uint16_t *_
 
     auto issue_x = [&](int s) {  // waves 0..3
         if (s * WK + wave >= nblk) return;  // wave-uniform (ragged last step)
-        uint8_t *slot = s_raw + ((s & 1) * WK + wave) * kSlot;
+        uint8_t *slot = s_raw + ((s % DX) * WK + wave) * kSlot;
 #pragma unroll
         for (int d = 0; d < 2 * NT; ++d) lds_dma16(xb + xoff[d] + (uint32_t)(s * WK + wave) * 128u, slot + d * 1024);
     };
@@ -194,23 +197,26 @@ __global__ __launch_bounds__(512) void gemm16_wide_ring_kernel(const uint16_t *_
     if (loader) {
         for (int s = 0; s < kDw - 1 && s < steps; ++s) issue_w(s);
     } else {
-        issue_x(0);
+        for (int s = 0; s < DX - 1 && s < steps; ++s) issue_x(s);
     }
     for (int s = 0; s < steps; ++s) {
-        // step s has landed: the x wave's only outstanding DMAs are step s's; a loader wave may keep the kDw - 2 younger steps in flight
+        // step s has landed; a loader wave may keep the kDw - 2 younger steps in flight, an x wave DX - 2 (not in the last steps,
+        // where a ragged step issues fewer DMAs than the count assumes)
         if (loader && s + kDw - 2 < steps)
             wait_vmcnt<(kDw - 2) * kPerStep>();
+        else if (!loader && s + DX - 2 < steps - 1)
+            wait_vmcnt<(DX - 2) * 2 * NT>();
         else
             wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (loader) {
             if (s + kDw - 1 < steps) issue_w(s + kDw - 1);  // into the slot step s - 1 used
-        } else if (s + 1 < steps) {
-            issue_x(s + 1);
+        } else if (s + DX - 1 < steps) {
+            issue_x(s + DX - 1);
         }
         if (s * WK + wk >= nblk) continue;  // wave-uniform (ragged last step): no block for this K slice
-        const uint8_t *xs = s_raw + ((s & 1) * WK + wk) * kSlot;
+        const uint8_t *xs = s_raw + ((s % DX) * WK + wk) * kSlot;
         const uint8_t *ws = s_w + (s % kDw) * kWSlot;
         const uint8_t *ss = s_s + (s % kDw) * kSSlot;
         u32x2 wq[RT];
