@@ -94,15 +94,15 @@ __device__ __forceinline__ void wide_epilogue(uint8_t *s_raw, const f32x4 (&acc)
     }
 }
 
-// ---- tall weights: 32*RT rows per workgroup, the weight stream seven steps deep ---------------------------------------------------
+// ---- tall weights: 32*RT rows per workgroup -------------------------------------------------------------------------------------
 // Fragment-shaped weight loads (8 bytes per lane from 16 different rows) keep the texture path busy for four cache-line lookups
-// per quad, and a load issued inside the step loop can only be one step deep: the LDS-DMA of x shares the in-order load counter, and
-// waiting for x retires every older load with it.  Here WR = 2, WK = 4 and
-//   * per step the workgroup's 32*RT rows x 128 B of weight (the four K slices' blocks are one full line per row) and their
-//     32*RT x 4 scales are fetched by waves 4..7 with LDS-DMA in full lines into a ring of kDw steps; these waves issue nothing
-//     else, so a counted s_waitcnt vmcnt leaves kDw - 2 steps of weight in flight across every barrier;
-//   * the x images are fetched by waves 0..3 (wave w: K slice w) DX - 1 steps ahead, whose counter holds nothing else: counted too;
-//   * the barrier is the bare s_barrier (a __syncthreads() fence would drain every wave's counter);
+// per quad, so the weight comes by LDS-DMA in full lines too: WR = 2, WK = 4, and per step the workgroup's 32*RT rows x 128 B of
+// weight (the four K slices' blocks are one full line per row) and their 32*RT x 4 scales.
+//   * ONE ring of D = 3..4 steps for x, weight and scales; every wave issues a share of each for step s + D - 1, so all eight waves
+//     carry about the same number of LDS-DMA issues per step (a first form had waves 0..3 fetch x and waves 4..7 the weight into a
+//     deeper ring of its own: 4-8 % slower - a step here is long enough for D - 1 steps to cover the HBM latency);
+//   * a counted s_waitcnt vmcnt leaves D - 2 steps in flight across the barrier, which is the bare s_barrier (a __syncthreads()
+//     fence would drain every wave's counter);
 //   * weight image: [row][128 B] with 16-byte piece ^ (row >> 1 & 7), applied to the DMA's source and to the ds_read_b64.
 
 template <int N>
@@ -115,48 +115,44 @@ __global__ __launch_bounds__(512) void gemm16_wide_ring_kernel(const uint16_t *_
                                                                const float *__restrict__ absmax, const uint16_t *__restrict__ bias,
                                                                const uint16_t *residual, uint16_t *out, int B, int M, int K, int mode) {
     constexpr int WR = 2, WK = 4, kTiles = WR * RT, kRows = 16 * kTiles;
-    // ring depths (LDS decides): x DX slots per K slice, weight kDw steps.  A step of this kernel is long (up to 16 MFMAs per wave), so
-    // three to four steps of weight in flight cover the HBM latency; what is left of the LDS goes to x.
-    constexpr int DX = (RT == 2 && NT == 4) ? 3 : 4;
-    constexpr int kDw = RT == 2 ? (NT == 4 ? 4 : (NT == 3 ? 5 : 8)) : (NT == 4 ? 6 : 8);
-    constexpr int kSlot = NT * 2048, kXRing = DX * WK * kSlot;
+    // ONE ring depth D for x and weight: every wave issues a share of both for step s + D - 1 (x: the K slice wave & 3, every second
+    // 8-column piece; weight: 8 rows x 128 B; waves 4..7 also 16 (8) rows of scales)
+    constexpr int kSlot = NT * 2048;
     constexpr int kWSlot = kRows * 128, kSSlot = kRows * 16;
+    constexpr int kPerDepth = WK * kSlot + kWSlot + kSSlot;
+    constexpr int D = (4 * kPerDepth <= 150 * 1024) ? 4 : 3;
+    constexpr int kXRing = D * WK * kSlot;
     constexpr int kPart = WK * kTiles * NT * 1024;
     constexpr int kXBytes = kXRing > kPart ? kXRing : kPart;
-    constexpr int kWDma = kRows / 8 / 4;   // weight DMAs (8 rows x 128 B) per loader wave and step: 2 (RT = 2) or 1
-    constexpr int kPerStep = kWDma + 1;    // + one scale DMA (4 bytes per lane: 16 rows x 4 scales, or 8 rows with half the lanes)
-    __shared__ __attribute__((aligned(1024))) uint8_t s_raw[kXBytes + kDw * (kWSlot + kSSlot)];
-    uint8_t *s_w = s_raw + kXBytes, *s_s = s_w + kDw * kWSlot;
+    static_assert(kXBytes + D * (kWSlot + kSSlot) <= 160 * 1024, "LDS");
+    __shared__ __attribute__((aligned(1024))) uint8_t s_raw[kXBytes + D * (kWSlot + kSSlot)];
+    uint8_t *s_w = s_raw + kXBytes, *s_s = s_w + D * kWSlot;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave % WR, wk = wave / WR;
     const int i = lane & 15, kb = lane >> 4;
     const int row0 = blockIdx.x * kRows;
     const int nblk = K >> 6, steps = (nblk + WK - 1) / WK;  // K % 256 != 0: ragged last step, handled as in the 16-row kernel below
-    const bool loader = wave >= 4;  // wave-uniform
 
-    // x: wave w < 4 fills K slice w: DMA d -> columns 8d .. 8d+7
-    uint32_t xoff[2 * NT];
+    const bool upper = wave >= 4;  // wave-uniform
+    const int xs_slice = wave & 3;
+    // x: waves w and w + 4 share K slice w: piece d = 2e + (wave >> 2) -> columns 8d .. 8d+7
+    uint32_t xoff[NT];
 #pragma unroll
-    for (int d = 0; d < 2 * NT; ++d) {
+    for (int e = 0; e < NT; ++e) {
+        const int d = 2 * e + (wave >> 2);
         const int n = 8 * d + (lane >> 3), sl = lane & 7;
         const int nn = n < B ? n : B - 1;
-        xoff[d] = (uint32_t)nn * (uint32_t)K * 2u + (uint32_t)((sl ^ ((n >> 1) & 7)) * 16);
+        xoff[e] = (uint32_t)nn * (uint32_t)K * 2u + (uint32_t)((sl ^ ((n >> 1) & 7)) * 16);
     }
     const uint8_t *xb = reinterpret_cast<const uint8_t *>(x);
-    // weights: loader wave v = wave - 4, DMA d -> rows 8*(v*kWDma + d) .. +7 of the workgroup; lane -> (row, 16-byte piece)
-    const uint8_t *wsrc[kWDma];
-    int wpiece[kWDma];
-#pragma unroll
-    for (int d = 0; d < kWDma; ++d) {
-        const int rl = 8 * (((wave - 4) & 3) * kWDma + d) + (lane >> 3), sl = lane & 7;
-        const int r = row0 + rl;
-        const int64_t row = r < M ? r : M - 1;
-        wpiece[d] = sl ^ ((rl >> 1) & 7);
-        wsrc[d] = W + row * (int64_t)(K >> 1);
-    }
-    // scales: lane -> (row, K slice); RT = 2: 16 rows per loader wave, RT = 1: 8 rows (lanes 0..31)
+    // weight: wave w fetches rows 8w .. 8w+7 of the workgroup (RT = 1: waves 0..3 only); lane -> (row, 16-byte piece)
+    constexpr bool kAllWavesLoadW = kRows == 64;
+    const int wrl = 8 * (kAllWavesLoadW ? wave : (wave & 3)) + (lane >> 3);
+    const int wpiece = (lane & 7) ^ ((wrl >> 1) & 7);
+    const uint8_t *wsrc = W + (int64_t)(row0 + wrl < M ? row0 + wrl : M - 1) * (int64_t)(K >> 1);
+    // scales: waves 4..7; lane -> (row, K slice); RT = 2: 16 rows each, RT = 1: 8 rows (lanes 0..31)
     constexpr int kSRows = kRows / 4;
-    const int srl = ((wave - 4) & 3) * kSRows + (lane >> 2);
+    const int srl = (wave & 3) * kSRows + (lane >> 2);
     const int srow = row0 + srl;
     const float *ssrc = absmax + (int64_t)(srow < M ? srow : M - 1) * nblk;
     const bool slane = (lane >> 2) < kSRows;
@@ -177,48 +173,43 @@ __global__ __launch_bounds__(512) void gemm16_wide_ring_kernel(const uint16_t *_
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[rt][nt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 
-    auto issue_x = [&](int s) {  // waves 0..3
-        if (s * WK + wave >= nblk) return;  // wave-uniform (ragged last step)
-        uint8_t *slot = s_raw + ((s % DX) * WK + wave) * kSlot;
+    // DMAs of this wave per step: x NT (none where the slice has no block: ragged last step), weight 1 (RT = 1: waves 0..3),
+    // scales 1 (waves 4..7)
+    constexpr int kGroupLo = NT + 1, kGroupHi = NT + (kAllWavesLoadW ? 2 : 1);
+    auto issue = [&](int s) {
+        const int ring = s % D, left = nblk - s * WK;
+        if (s * WK + xs_slice < nblk) {  // wave-uniform
+            uint8_t *slot = s_raw + (ring * WK + xs_slice) * kSlot;
 #pragma unroll
-        for (int d = 0; d < 2 * NT; ++d) lds_dma16(xb + xoff[d] + (uint32_t)(s * WK + wave) * 128u, slot + d * 1024);
-    };
-    auto issue_w = [&](int s) {  // waves 4..7
-        const int ring = s % kDw, left = nblk - s * WK;
-#pragma unroll
-        for (int d = 0; d < kWDma; ++d)
-            lds_dma16(wsrc[d] + s * 128 + ((wpiece[d] >> 1) < left ? wpiece[d] * 16 : 0),
-                      s_w + ring * kWSlot + (((wave - 4) & 3) * kWDma + d) * 1024);
-        if (slane)
+            for (int e = 0; e < NT; ++e)
+                lds_dma16(xb + xoff[e] + (uint32_t)(s * WK + xs_slice) * 128u, slot + (2 * e + (wave >> 2)) * 1024);
+        }
+        if (kAllWavesLoadW || !upper)
+            lds_dma16(wsrc + s * 128 + ((wpiece >> 1) < left ? wpiece * 16 : 0),
+                      s_w + ring * kWSlot + (kAllWavesLoadW ? wave : (wave & 3)) * 1024);
+        if (upper && slane)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ssrc + s * 4 + ((lane & 3) < left ? (lane & 3) : 0)),
-                                             (__attribute__((address_space(3))) void *)(s_s + ring * kSSlot + ((wave - 4) & 3) * kSRows * 16),
+                                             (__attribute__((address_space(3))) void *)(s_s + ring * kSSlot + (wave & 3) * kSRows * 16),
                                              4, 0, 0);
     };
-    if (loader) {
-        for (int s = 0; s < kDw - 1 && s < steps; ++s) issue_w(s);
-    } else {
-        for (int s = 0; s < DX - 1 && s < steps; ++s) issue_x(s);
-    }
+    for (int s = 0; s < D - 1 && s < steps; ++s) issue(s);
     for (int s = 0; s < steps; ++s) {
-        // step s has landed; a loader wave may keep the kDw - 2 younger steps in flight, an x wave DX - 2 (not in the last steps,
-        // where a ragged step issues fewer DMAs than the count assumes)
-        if (loader && s + kDw - 2 < steps)
-            wait_vmcnt<(kDw - 2) * kPerStep>();
-        else if (!loader && s + DX - 2 < steps - 1)
-            wait_vmcnt<(DX - 2) * 2 * NT>();
-        else
+        // step s has landed; D - 2 younger steps may stay in flight (not near the end, where a ragged step issues fewer DMAs)
+        if (s + D - 2 < steps - 1) {
+            if (upper)
+                wait_vmcnt<(D - 2) * kGroupHi>();
+            else
+                wait_vmcnt<(D - 2) * kGroupLo>();
+        } else {
             wait_vmcnt<0>();
+        }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (loader) {
-            if (s + kDw - 1 < steps) issue_w(s + kDw - 1);  // into the slot step s - 1 used
-        } else if (s + DX - 1 < steps) {
-            issue_x(s + DX - 1);
-        }
+        if (s + D - 1 < steps) issue(s + D - 1);  // into the slots step s - 1 used
         if (s * WK + wk >= nblk) continue;  // wave-uniform (ragged last step): no block for this K slice
-        const uint8_t *xs = s_raw + ((s % DX) * WK + wk) * kSlot;
-        const uint8_t *ws = s_w + (s % kDw) * kWSlot;
-        const uint8_t *ss = s_s + (s % kDw) * kSSlot;
+        const uint8_t *xs = s_raw + ((s % D) * WK + wk) * kSlot;
+        const uint8_t *ws = s_w + (s % D) * kWSlot;
+        const uint8_t *ss = s_s + (s % D) * kSSlot;
         u32x2 wq[RT];
         float am[RT];
 #pragma unroll
