@@ -106,6 +106,8 @@ def gemm_small(x: torch.Tensor, packed: torch.Tensor, absmax: torch.Tensor, M: i
     B = x.numel() // K
     out = torch.empty(B, M, dtype=x.dtype, device=x.device)
     rc = lib().fp4_hip_gemm_small(_ptr(x), _ptr(packed), _ptr(absmax), _ptr(bias), _ptr(out), B, M, K, blocksize, DT[x.dtype], _stream())
+    if expect_ok is None:  # the caller looks at both
+        return rc, out
     if expect_ok:
         assert rc == OK, (rc, last_error())
         return out

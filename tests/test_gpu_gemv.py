@@ -371,6 +371,40 @@ def test_wide_batch_one_pass_kernel(dtype, cfg, B, M, K):
     assert (err <= HALF_ULP[dtype] * 1.01 * np.abs(exact) + 1e-5 * scale + 1e-30).all(), float(err.max())
 
 
+def test_small_batch_random_shapes_against_float64():
+    """200 seeded random cases through fp4_hip_gemm_small: 1..128 rows, M in 1..200, K = 64 * (1..40) - fewer quant blocks than K
+    slices, ragged last steps, single-row weights, every workgroup shape of the one-pass kernels forced or chosen - against the
+    float64 product (the GEMV's bar).  Shapes no kernel covers must be refused, never computed wrongly."""
+    rng = np.random.default_rng(20260)
+    for case in range(200):
+        K = 64 * int(rng.integers(1, 41))
+        M = int(rng.integers(1, 201))
+        B = int(rng.integers(1, 129))
+        dtype = (torch.bfloat16, torch.float16)[case & 1]
+        cfg = int(rng.integers(-1, 4))
+        w = (rng.standard_normal(M * K) * 0.03).astype(np.float32)
+        packed, am = c_oracle.quantize(w, 64)
+        x_t = torch_values(rng.standard_normal((B, K)).astype(np.float32), dtype)
+        b_t = torch_values(rng.standard_normal(M).astype(np.float32) * 0.1, dtype) if case % 3 else None
+        hipabi.set_variant("gemm_wide", cfg)
+        try:
+            rc, y = hipabi.gemm_small(x_t, to_dev(packed), to_dev(am), M, K, 64, bias=b_t, expect_ok=None)
+        finally:
+            hipabi.set_variant("gemm_wide", -1)
+        if rc != hipabi.OK:
+            # refused: only legal where neither the 16-row kernels (K % 512, or <= 8 rows on short rows) nor the one-pass ones
+            # (switched off by cfg 0 for > 16 rows) apply
+            assert rc == hipabi.ERR_UNSUPPORTED and cfg == 0 and B > 8 and K % 512, (case, B, M, K, cfg, hipabi.last_error())
+            continue
+        wd = o.dequantize_f32(packed, am, 64, M * K).reshape(M, K).astype(np.float64)
+        xv = x_t.float().cpu().numpy().astype(np.float64)
+        bv = np.zeros(M) if b_t is None else b_t.float().cpu().numpy().astype(np.float64)
+        exact = xv @ wd.T + bv
+        scale = np.abs(xv) @ np.abs(wd).T + np.abs(bv)
+        err = np.abs(y.float().cpu().numpy().astype(np.float64) - exact)
+        assert (err <= HALF_ULP[dtype] * 1.01 * np.abs(exact) + 1e-5 * scale + 1e-30).all(), (case, B, M, K, cfg, float(err.max()))
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_wide_batch_default_dispatch_and_row_limits(dtype):
     """Default dispatch: 17..64 rows take the one-pass kernel (the result differs from the 16-row launches only in summation
