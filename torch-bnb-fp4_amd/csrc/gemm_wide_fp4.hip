@@ -3,19 +3,23 @@
 // The reference sends every batch > 1 through a full dequant + dense GEMM (torch_bnb_fp4/__init__.py:423-436,616-617): at
 // 14336 x 4096 that is 150 MB written and read back for 33 MB of weight.  gemm_small_fp4.hip covers up to 16 rows per launch
 // (one 16-column matrix-core tile, x in registers); above that it used to stream the weight once per 16 rows.  Here one launch
-// multiplies every decoded weight fragment with NT = 2..4 column tiles of x:
+// multiplies every decoded weight fragment with NT = 2..4 column tiles of x (NT = 1 as well: 1..16 rows on K % 512 != 0, which
+// the kernels of gemm_small_fp4.hip do not take):
 //   * the compute waves of a workgroup are WR row groups x WK K slices; a wave owns RT 16-row tiles and every WK-th quant block;
 //   * per step (one 64-column quant block per K slice) the x operand - 16*NT columns x 128 B, L2-resident, by far the larger
-//     on-chip stream - goes into LDS in full 128-byte lines by LDS-DMA (global_load_lds_dwordx4, no VGPR staging), two ring
+//     on-chip stream - goes into LDS in full 128-byte lines by LDS-DMA (global_load_lds_dwordx4, no VGPR staging), 2..4 ring
 //     slots per K slice; the image is lane-linear, so the bank swizzle (16-byte unit ^ (column >> 1)) is applied to the SOURCE
 //     address and again to the ds_read_b128 address;
-//   * the weight and its block scales come by LDS-DMA as well, in full lines, from waves that issue nothing else, into a ring
-//     several steps deep (see the kernels); a first version loaded them fragment-shaped into registers one step ahead and spent
-//     more time on that than on everything else (profiles/r02_wide_batch_17_to_128_rows.txt);
+//   * the weight and its block scales come by LDS-DMA as well, in full lines, into a ring several steps deep (see the two kernels
+//     for who issues what); a first version loaded them fragment-shaped into registers one step ahead and spent more time on that
+//     than on everything else (profiles/r02_wide_batch_17_to_128_rows.txt);
+//   * waits are counted (s_waitcnt vmcnt(N) in front of a bare s_barrier), so younger steps stay in flight across the barrier;
 //   * x is the A operand and the weight the B operand, so a lane's accumulators all belong to ONE weight row and the block scale is
 //     one scalar per lane;
 //   * decode8's (e0,e2)(e4,e6)(e1,e3)(e5,e7) pairs are put back into natural order (4 v_perm per 8 weights, amortised over the
 //     NT column tiles), so the x image needs no re-pairing;
+//   * any K % 64 == 0: in a ragged last step the K slices past the row's end skip their work, and DMA lanes past it re-read a
+//     valid piece;
 //   * K-slice partials meet in LDS (the ring's storage, after the loop) and are summed in a fixed order: deterministic.
 #include <atomic>
 
