@@ -184,6 +184,13 @@ def test_fused_layers_match_the_unfused_modules_and_capture_into_a_graph():
     got2 = dn(gu(h2), residual=h2)
     want2 = h2 + fp[2](torch.nn.functional.silu(fp[0](h2)) * fp[1](h2))
     assert got2.shape == want2.shape and (got2.float() - want2.float()).abs().max() <= 2e-2 * want2.float().abs().max()
+    # 40 and 100 rows (I = 1408 = 22 quant blocks: the one-pass kernels with a ragged last step; 100 rows: two chunks), 3-D input
+    for rows in (40, 100):
+        hb = (torch.randn(rows, H, generator=g) * 0.5).to(torch.bfloat16).to(dev()).view(2, rows // 2, H)
+        gotb = dn(gu(hb), residual=hb)
+        wantb = hb + fp[2](torch.nn.functional.silu(fp[0](hb)) * fp[1](hb))
+        assert gotb.shape == wantb.shape == (2, rows // 2, H)
+        assert (gotb.float() - wantb.float()).abs().max() <= 2e-2 * wantb.float().abs().max()
 
 
 @pytest.mark.parametrize("dtype", DT16)
