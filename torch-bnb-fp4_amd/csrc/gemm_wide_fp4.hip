@@ -259,8 +259,8 @@ __global__ __launch_bounds__(640) void gemm16_wide_ring8_kernel(const uint16_t *
                                                                 const float *__restrict__ absmax, const uint16_t *__restrict__ bias,
                                                                 const uint16_t *residual, uint16_t *out, int B, int M, int K, int mode) {
     // ring depths: x DX slots per K slice (DX - 2 steps of x stay in flight across a barrier), weight DW steps; LDS decides:
-    // NT = 1: 64 + 36 KB, NT = 2: 128 + 27 KB, NT = 3: 96 + 36 KB, NT = 4: 128 + 27 KB
-    constexpr int WK = 8, DX = NT <= 2 ? 4 : 2, DW = (NT == 4 || NT == 2) ? 6 : 8;
+    // NT = 1: 64 + 36 KB, NT = 2: 128 + 27 KB, NT = 3: 144 + 13.5 KB, NT = 4: 128 + 27 KB
+    constexpr int WK = 8, DX = NT <= 2 ? 4 : (NT == 3 ? 3 : 2), DW = NT == 3 ? 3 : ((NT == 4 || NT == 2) ? 6 : 8);
     constexpr int kSlot = NT * 2048, kXRing = DX * WK * kSlot;
     constexpr int kWSlot = 16 * 256, kSSlot = 16 * 32;
     constexpr int kPart = WK * NT * 1024;
