@@ -52,7 +52,7 @@ int main(int argc, char **argv) {
     hipStream_t s;
     CK(hipStreamCreate(&s));
     printf("%dx%d, %d rows, us per launch by rows per workgroup:", M, K, B);
-    for (int cfg : {1, 2, 3}) {
+    for (int cfg : {1, 2, 3, 4}) {
         fp4::set_wide_variant(cfg);
         auto pass = [&]() {
             for (int i = 0; i < R; ++i)

@@ -126,11 +126,11 @@ __global__ __launch_bounds__(512) void gemm16_wide_ring_kernel(const uint16_t *_
     constexpr int kPerDepth = WK * kSlot + kWSlot + kSSlot;
     constexpr int D = (4 * kPerDepth <= 150 * 1024) ? 4 : 3;
     constexpr int kXRing = D * WK * kSlot;
-    constexpr int kPart = WK * kTiles * NT * 1024;
-    constexpr int kXBytes = kXRing > kPart ? kXRing : kPart;
-    static_assert(kXBytes + D * (kWSlot + kSSlot) <= 160 * 1024, "LDS");
-    __shared__ __attribute__((aligned(1024))) uint8_t s_raw[kXBytes + D * (kWSlot + kSSlot)];
-    uint8_t *s_w = s_raw + kXBytes, *s_s = s_w + D * kWSlot;
+    constexpr int kPart = WK * kTiles * NT * 1024;  // (the partials reuse the rings' storage after the loop)
+    constexpr int kRings = kXRing + D * (kWSlot + kSSlot);
+    static_assert((kRings > kPart ? kRings : kPart) <= 160 * 1024, "LDS");
+    __shared__ __attribute__((aligned(1024))) uint8_t s_raw[kRings > kPart ? kRings : kPart];
+    uint8_t *s_w = s_raw + kXRing, *s_s = s_w + D * kWSlot;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave % WR, wk = wave / WR;
     const int i = lane & 15, kb = lane >> 4;
@@ -149,16 +149,25 @@ __global__ __launch_bounds__(512) void gemm16_wide_ring_kernel(const uint16_t *_
         xoff[e] = (uint32_t)nn * (uint32_t)K * 2u + (uint32_t)((sl ^ ((n >> 1) & 7)) * 16);
     }
     const uint8_t *xb = reinterpret_cast<const uint8_t *>(x);
-    // weight: wave w fetches rows 8w .. 8w+7 of the workgroup (RT = 1: waves 0..3 only); lane -> (row, 16-byte piece)
-    constexpr bool kAllWavesLoadW = kRows == 64;
-    const int wrl = 8 * (kAllWavesLoadW ? wave : (wave & 3)) + (lane >> 3);
-    const int wpiece = (lane & 7) ^ ((wrl >> 1) & 7);
-    const uint8_t *wsrc = W + (int64_t)(row0 + wrl < M ? row0 + wrl : M - 1) * (int64_t)(K >> 1);
-    // scales: waves 4..7; lane -> (row, K slice); RT = 2: 16 rows each, RT = 1: 8 rows (lanes 0..31)
-    constexpr int kSRows = kRows / 4;
-    const int srl = (wave & 3) * kSRows + (lane >> 2);
-    const int srow = row0 + srl;
-    const float *ssrc = absmax + (int64_t)(srow < M ? srow : M - 1) * nblk;
+    // weight: 8 rows x 128 B per DMA; RT = 4: two per wave, RT = 2: one per wave, RT = 1: one per wave 0..3; lane -> (row, piece)
+    constexpr int kWD = RT == 4 ? 2 : 1;
+    constexpr bool kAllWavesLoadW = RT >= 2;
+    const uint8_t *wsrc[kWD];
+    int wpiece[kWD];
+#pragma unroll
+    for (int d = 0; d < kWD; ++d) {
+        const int wrl = 8 * ((kAllWavesLoadW ? wave : (wave & 3)) * kWD + d) + (lane >> 3);
+        wpiece[d] = (lane & 7) ^ ((wrl >> 1) & 7);
+        wsrc[d] = W + (int64_t)(row0 + wrl < M ? row0 + wrl : M - 1) * (int64_t)(K >> 1);
+    }
+    // scales: waves 4..7, 16 rows x 4 scales per DMA (RT = 4: two, RT = 1: 8 rows with lanes 0..31); lane -> (row, K slice)
+    constexpr int kSRows = kRows / 4, kSD = RT == 4 ? 2 : 1;
+    const float *ssrc[kSD];
+#pragma unroll
+    for (int d = 0; d < kSD; ++d) {
+        const int srow = row0 + (wave & 3) * kSRows + d * 16 + (lane >> 2);
+        ssrc[d] = absmax + (int64_t)(srow < M ? srow : M - 1) * nblk;
+    }
     const bool slane = (lane >> 2) < kSRows;
 
     // fragment reads
@@ -177,9 +186,9 @@ __global__ __launch_bounds__(512) void gemm16_wide_ring_kernel(const uint16_t *_
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[rt][nt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 
-    // DMAs of this wave per step: x NT (none where the slice has no block: ragged last step), weight 1 (RT = 1: waves 0..3),
-    // scales 1 (waves 4..7)
-    constexpr int kGroupLo = NT + 1, kGroupHi = NT + (kAllWavesLoadW ? 2 : 1);
+    // DMAs of this wave per step: x NT (none where the slice has no block: ragged last step), weight kWD (RT = 1: waves 0..3 only),
+    // scales kSD (waves 4..7)
+    constexpr int kGroupLo = NT + kWD, kGroupHi = NT + (kAllWavesLoadW ? kWD : 0) + kSD;
     auto issue = [&](int s) {
         const int ring = s % D, left = nblk - s * WK;
         if (s * WK + xs_slice < nblk) {  // wave-uniform
@@ -188,13 +197,19 @@ __global__ __launch_bounds__(512) void gemm16_wide_ring_kernel(const uint16_t *_
             for (int e = 0; e < NT; ++e)
                 lds_dma16(xb + xoff[e] + (uint32_t)(s * WK + xs_slice) * 128u, slot + (2 * e + (wave >> 2)) * 1024);
         }
-        if (kAllWavesLoadW || !upper)
-            lds_dma16(wsrc + s * 128 + ((wpiece >> 1) < left ? wpiece * 16 : 0),
-                      s_w + ring * kWSlot + (kAllWavesLoadW ? wave : (wave & 3)) * 1024);
-        if (upper && slane)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ssrc + s * 4 + ((lane & 3) < left ? (lane & 3) : 0)),
-                                             (__attribute__((address_space(3))) void *)(s_s + ring * kSSlot + (wave & 3) * kSRows * 16),
-                                             4, 0, 0);
+        if (kAllWavesLoadW || !upper) {
+#pragma unroll
+            for (int d = 0; d < kWD; ++d)
+                lds_dma16(wsrc[d] + s * 128 + ((wpiece[d] >> 1) < left ? wpiece[d] * 16 : 0),
+                          s_w + ring * kWSlot + ((kAllWavesLoadW ? wave : (wave & 3)) * kWD + d) * 1024);
+        }
+        if (upper && slane) {
+#pragma unroll
+            for (int d = 0; d < kSD; ++d)
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void *)(ssrc[d] + s * 4 + ((lane & 3) < left ? (lane & 3) : 0)),
+                    (__attribute__((address_space(3))) void *)(s_s + ring * kSSlot + ((wave & 3) * kSRows + d * 16) * 16), 4, 0, 0);
+        }
     };
     for (int s = 0; s < D - 1 && s < steps; ++s) issue(s);
     for (int s = 0; s < steps; ++s) {
@@ -369,12 +384,12 @@ __global__ __launch_bounds__(640) void gemm16_wide_ring8_kernel(const uint16_t *
     wide_epilogue<DT, NT, 1, 1, 640>(s_raw, acc, bias, residual, out, B, M, row0, mode);
 }
 
-std::atomic<int> g_wide_cfg{-1};  // -1 heuristic; 0 = never (16-row launches); 1 / 2 / 3 = 16 / 32 / 64 rows per workgroup
+std::atomic<int> g_wide_cfg{-1};  // -1 heuristic; 0 = never (16-row launches); 1 / 2 / 3 / 4 = 16 / 32 / 64 / 128 rows per workgroup
 
 template <int DT, int NT>
 int dispatch_wide_cfg(int cfg, const void *x, const uint8_t *W, const float *absmax, const void *bias, const void *residual, void *out,
                       int B, int M, int K, int mode, hipStream_t stream) {
-    const unsigned rows = cfg == 1 ? 16u : (cfg == 2 ? 32u : 64u);
+    const unsigned rows = cfg == 1 ? 16u : (cfg == 2 ? 32u : (cfg == 3 ? 64u : 128u));
     const dim3 grid(((unsigned)M + rows - 1) / rows);
 #define FP4_WIDE_ARGS reinterpret_cast<const uint16_t *>(x), W, absmax, reinterpret_cast<const uint16_t *>(bias), \
                       reinterpret_cast<const uint16_t *>(residual), reinterpret_cast<uint16_t *>(out), B, M, K, mode
@@ -382,8 +397,10 @@ int dispatch_wide_cfg(int cfg, const void *x, const uint8_t *W, const float *abs
         hipLaunchKernelGGL((gemm16_wide_ring8_kernel<DT, NT>), grid, dim3(640), 0, stream, FP4_WIDE_ARGS);
     else if (cfg == 2)
         hipLaunchKernelGGL((gemm16_wide_ring_kernel<DT, NT, 1>), grid, dim3(512), 0, stream, FP4_WIDE_ARGS);
-    else
+    else if (cfg == 3)
         hipLaunchKernelGGL((gemm16_wide_ring_kernel<DT, NT, 2>), grid, dim3(512), 0, stream, FP4_WIDE_ARGS);
+    else
+        hipLaunchKernelGGL((gemm16_wide_ring_kernel<DT, NT, 4>), grid, dim3(512), 0, stream, FP4_WIDE_ARGS);
 #undef FP4_WIDE_ARGS
     return FP4_OK;
 }
@@ -400,7 +417,7 @@ int dispatch_wide(int cfg, const void *x, const uint8_t *W, const float *absmax,
 
 }  // namespace
 
-void set_wide_variant(int v) { g_wide_cfg = v < 0 ? -1 : (v > 3 ? 3 : v); }
+void set_wide_variant(int v) { g_wide_cfg = v < 0 ? -1 : (v > 4 ? 4 : v); }
 
 // 17..64 activation rows (any_rows: 1..64 - the caller's other kernels do not cover the shape), 16-bit dtype, blocksize 64,
 // K % 64 == 0, 16-byte aligned operands.  Returns FP4_OK after the launch, or -1 when the shape is not covered / the path is switched
@@ -411,10 +428,10 @@ int gemm_wide_launch(int dtype, const void *x, const uint8_t *W, const float *ab
     if (cfg == 0 || B < 1 || (B <= 16 && !any_rows) || B > 64 || (K % 64) != 0 || M < 1) return -1;
     if ((uint64_t)B * (uint64_t)K * 2u >= (uint64_t(1) << 32)) return -1;  // 32-bit x offsets
     if (cfg < 0) {
-        // Measured (profiles/r02_wide_batch_17_to_128_rows.txt, MI355X): 64 rows per workgroup once that fills three quarters of the
-        // chip, 32 rows from half of that, below it 16 rows with two loader waves - all three with every stream by LDS-DMA.
+        // Measured (profiles/r02_wide_batch_17_to_128_rows.txt, MI355X): the tallest workgroup that still fills three quarters of the
+        // chip - 128 rows (four tiles per wave), 64, 32 - and below that 16 rows with two loader waves.
         const int cus = device_cu_count();
-        cfg = M >= 48 * cus ? 3 : (M >= 24 * cus ? 2 : 1);
+        cfg = M >= 96 * cus ? 4 : (M >= 48 * cus ? 3 : (M >= 24 * cus ? 2 : 1));
     }
     return dtype == FP4_DTYPE_F16 ? dispatch_wide<FP4_DTYPE_F16>(cfg, x, W, absmax, bias, residual, out, B, M, K, mode, stream)
                                   : dispatch_wide<FP4_DTYPE_BF16>(cfg, x, W, absmax, bias, residual, out, B, M, K, mode, stream);
