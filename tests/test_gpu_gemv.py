@@ -233,15 +233,16 @@ def test_partial_f32_output_and_k_split_sum(dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("kernel", [0, 1 | (1 << 4), 1 | (2 << 4), 1 | (1 << 4) | (1 << 8), 1 | (2 << 4) | (1 << 8), 1 | (1 << 4) | (2 << 14)])  # VALU kernel; matrix-core kernel: 1 / 2 row tiles, LDS-staged / direct weight loads, 8 blocks per pass wherever they divide K
+@pytest.mark.parametrize("kernel", [-1, 0, 1 | (1 << 4), 1 | (2 << 4), 1 | (1 << 4) | (1 << 8), 1 | (2 << 4) | (1 << 8), 1 | (1 << 4) | (2 << 14)])  # VALU kernel; matrix-core kernel: 1 / 2 row tiles, LDS-staged / direct weight loads, 8 blocks per pass wherever they divide K
 @pytest.mark.parametrize("B", [1, 2, 3, 4, 5, 8, 9, 13, 16])
 @pytest.mark.parametrize("M,K", [(4096, 4096), (1024, 4096), (2048, 768), (66, 2048), (257, 1024), (300, 8192), (40, 14336), (33, 512),
-                                 (130, 11008), (48, 1472)])
+                                 (130, 11008), (48, 1472), (70, 5120), (36, 13824)])
 def test_small_batch_fused_gemm(dtype, kernel, B, M, K):
     """fp4_hip_gemm_small: 1..16 activation rows against the float64 product, same bar as the GEMV (one rounding);
     both kernels, every shape class (VALU band splits, MFMA blocks-per-wave 1/2/4/8, ragged M, B not a power of two).  K % 512 != 0
     beyond the VALU kernel's reach (11008 = Llama-2-7B's down projection, 1472 = 23 blocks) lands on the one-pass kernels of
-    gemm_wide_fp4.hip with one column tile and a ragged last step."""
+    gemm_wide_fp4.hip with one column tile and a ragged last step; so do, in the default dispatch, K = 5120 from 5 rows and K = 13824
+    (one or two quant blocks per wave and pass on the 16-row matrix-core kernel)."""
     packed, am, _ = make_case(M, K, seed=B * 1000 + M)
     rng = np.random.default_rng(B)
     x = rng.standard_normal((B, K)).astype(np.float32)

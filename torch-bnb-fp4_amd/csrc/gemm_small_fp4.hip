@@ -769,7 +769,16 @@ int gemm_small_entry(const void *x, const uint8_t *packed, const float *absmax, 
     const bool mfma_ok = ok && blocksize == 64 && (K % 512) == 0;
     const int v_small = g_small_variant.load(std::memory_order_relaxed);
     const bool want_mfma = v_small == 1 || (v_small < 0 && B >= 2);
-    if (mfma_ok && (want_mfma || B > 8))
+    // Row lengths that leave the matrix-core kernel below with one or two quant blocks per wave and pass (K / 512 odd: 13824; K / 512
+    // = 2 mod 4: 5120, 7168), and tall weights with long rows, are faster on the one-pass kernels of gemm_wide_fp4.hip with ONE
+    // column tile (profiles/r02_wide_batch_17_to_128_rows.txt: 5120 x 13824 x 16 rows 49.2 -> 26.9 us, 13824 x 5120 21.7 -> 15.6 us,
+    // 28672 x 8192 52.7 -> 38.8 us); up to 4 rows the old kernel holds where K / 512 is even.
+    if (mfma_ok && v_small < 0 && B >= 2) {
+        const int64_t units = K / 512;
+        if ((units & 1) || ((units % 4) != 0 && B >= 5) || (M >= 96 * int64_t(device_cu_count()) && K >= 8192 && B >= 5))
+            rc = gemm_wide_launch(dtype, x, packed, absmax, bias, residual, out, (int)B, (int)M, (int)K, mode, true, s);
+    }
+    if (rc == -1 && mfma_ok && (want_mfma || B > 8))
         rc = dtype == FP4_DTYPE_F16 ? dispatch_mfma<FP4_DTYPE_F16>(x, packed, absmax, bias, residual, out, (int)B, (int)M, (int)K, mode, s)
                                     : dispatch_mfma<FP4_DTYPE_BF16>(x, packed, absmax, bias, residual, out, (int)B, (int)M, (int)K, mode, s);
     if (rc == -1 && ok && B <= 8 && K <= 16384)

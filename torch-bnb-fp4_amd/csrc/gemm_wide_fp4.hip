@@ -431,7 +431,10 @@ int gemm_wide_launch(int dtype, const void *x, const uint8_t *W, const float *ab
         // Measured (profiles/r02_wide_batch_17_to_128_rows.txt, MI355X): the tallest workgroup that still fills three quarters of the
         // chip - 128 rows (four tiles per wave), 64, 32 - and below that 16 rows with two loader waves.
         const int cus = device_cu_count();
-        cfg = M >= 96 * cus ? 4 : (M >= 48 * cus ? 3 : (M >= 24 * cus ? 2 : 1));
+        if (B <= 16)  // one column tile: little x to share, 32 rows from 5120 rows on, never 128
+            cfg = M >= 48 * cus ? 3 : (M >= 20 * cus ? 2 : 1);
+        else
+            cfg = M >= 96 * cus ? 4 : (M >= 48 * cus ? 3 : (M >= 24 * cus ? 2 : 1));
     }
     return dtype == FP4_DTYPE_F16 ? dispatch_wide<FP4_DTYPE_F16>(cfg, x, W, absmax, bias, residual, out, B, M, K, mode, stream)
                                   : dispatch_wide<FP4_DTYPE_BF16>(cfg, x, W, absmax, bias, residual, out, B, M, K, mode, stream);
