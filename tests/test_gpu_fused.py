@@ -194,7 +194,7 @@ def test_fused_layers_match_the_unfused_modules_and_capture_into_a_graph():
 
 
 @pytest.mark.parametrize("dtype", DT16)
-@pytest.mark.parametrize("wide", [-1, 0, 1, 2, 3, 4])  # 17..64 rows: default dispatch, 16-row launches, the one-pass kernels' 16 / 32 / 64 / 128-row workgroups
+@pytest.mark.parametrize("wide", [-1, 0, 1, 2, 3, 4, 5])  # 17..64 rows: default dispatch, 16-row launches, the one-pass kernels' 16 / 32 / 64 / 128-row workgroups
 @pytest.mark.parametrize("B", [24, 40, 64, 100])
 @pytest.mark.parametrize("M,K", [(4096, 4096), (258, 2048), (130, 14336), (66, 1024)])
 def test_wide_batch_epilogues(dtype, wide, B, M, K):

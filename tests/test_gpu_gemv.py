@@ -342,7 +342,7 @@ def wide_case(M, K):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("cfg", [1, 2, 3, 4])  # 16 / 32 / 64 / 128 rows per workgroup
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5])  # 16 / 32 / 64 / 128 rows per workgroup; 5: the barrier-free 16-row kernel (up to 32 rows)
 @pytest.mark.parametrize("B", [17, 24, 32, 33, 40, 48, 49, 64])
 @pytest.mark.parametrize("M,K", WIDE_SHAPES)
 def test_wide_batch_one_pass_kernel(dtype, cfg, B, M, K):
@@ -382,7 +382,7 @@ def test_small_batch_random_shapes_against_float64():
         M = int(rng.integers(1, 201))
         B = int(rng.integers(1, 129))
         dtype = (torch.bfloat16, torch.float16)[case & 1]
-        cfg = int(rng.integers(-1, 5))
+        cfg = int(rng.integers(-1, 6))
         w = (rng.standard_normal(M * K) * 0.03).astype(np.float32)
         packed, am = c_oracle.quantize(w, 64)
         x_t = torch_values(rng.standard_normal((B, K)).astype(np.float32), dtype)

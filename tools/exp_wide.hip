@@ -52,7 +52,7 @@ int main(int argc, char **argv) {
     hipStream_t s;
     CK(hipStreamCreate(&s));
     printf("%dx%d, %d rows, us per launch by rows per workgroup:", M, K, B);
-    for (int cfg : {1, 2, 3, 4}) {
+    for (int cfg : {1, 2, 3, 4, 5}) {
         fp4::set_wide_variant(cfg);
         auto pass = [&]() {
             for (int i = 0; i < R; ++i)
@@ -79,7 +79,7 @@ int main(int argc, char **argv) {
             CK(hipEventElapsedTime(&ms, e0, e1));
             best = ms < best ? ms : best;
         }
-        printf("  %d rows: %6.2f", 8 << cfg, best * 1e3f / R);
+        if (cfg == 5) printf("  auto16: %6.2f", best * 1e3f / R); else printf("  %d rows: %6.2f", 8 << cfg, best * 1e3f / R);
         CK(hipGraphExecDestroy(ge));
         CK(hipGraphDestroy(g));
     }

@@ -384,15 +384,122 @@ __global__ __launch_bounds__(640) void gemm16_wide_ring8_kernel(const uint16_t *
     wide_epilogue<DT, NT, 1, 1, 640>(s_raw, acc, bias, residual, out, B, M, row0, mode);
 }
 
-std::atomic<int> g_wide_cfg{-1};  // -1 heuristic; 0 = never (16-row launches); 1 / 2 / 3 / 4 = 16 / 32 / 64 / 128 rows per workgroup
+// ---- up to 32 rows on short weights: eight self-contained waves, no barrier in the K loop ------------------------------------------
+// 16 rows per workgroup, K split 8 ways, and every wave fetches ITS OWN operands - x, weight and scales of two consecutive quant
+// blocks per step - into wave-private ring slots: nothing another wave reads, so the loop needs no workgroup barrier, only the
+// wave's own counted s_waitcnt (one queue, every step the same 4*NT + 2 DMAs, D - 2 steps left in flight).  A step's two blocks are
+// 64 contiguous bytes per weight row (one DMA: 16 rows x 4 lanes) and give two independent ds_read -> decode -> MFMA -> scale chains;
+// the ring kernels above pay a barrier and one such chain per block, which is what bounds them at one or two column tiles
+// (4096 x 14336 x 16 rows: 0.6 us per step there).  Weight image: [row][64 B] with 16-byte piece ^ (row >> 2 & 3).
+template <int DT, int NT>
+__global__ __launch_bounds__(512) void gemm16_wide_auto_kernel(const uint16_t *__restrict__ x, const uint8_t *__restrict__ W,
+                                                               const float *__restrict__ absmax, const uint16_t *__restrict__ bias,
+                                                               const uint16_t *residual, uint16_t *out, int B, int M, int K, int mode) {
+    constexpr int WK = 8, D = NT == 1 ? 3 : 2;
+    constexpr int kXSlot = 2 * NT * 2048, kWaveSlot = kXSlot + 1024 + 256;  // x (2 blocks), weight (16 x 64 B), scales (16 x 2, padded)
+    constexpr int kWaveBytes = D * kWaveSlot;
+    constexpr int kPart = WK * NT * 1024;
+    static_assert(8 * kWaveBytes <= 160 * 1024 && kPart <= 8 * kWaveBytes, "LDS");
+    __shared__ __attribute__((aligned(1024))) uint8_t s_raw[8 * kWaveBytes];
+    const int tid = threadIdx.x, lane = tid & 63, wk = tid >> 6;
+    const int i = lane & 15, kb = lane >> 4;
+    const int row0 = blockIdx.x * 16;
+    const int nblk = K >> 6, steps = (nblk + 2 * WK - 1) / (2 * WK);
+    uint8_t *mine = s_raw + wk * kWaveBytes;
+
+    uint32_t xoff[2 * NT];
+#pragma unroll
+    for (int d = 0; d < 2 * NT; ++d) {
+        const int n = 8 * d + (lane >> 3), sl = lane & 7;
+        const int nn = n < B ? n : B - 1;
+        xoff[d] = (uint32_t)nn * (uint32_t)K * 2u + (uint32_t)((sl ^ ((n >> 1) & 7)) * 16);
+    }
+    const uint8_t *xb = reinterpret_cast<const uint8_t *>(x);
+    // weight: lane -> (row = lane >> 2, 16-byte piece of the step's 64 B); scales: lanes 0..31 -> (row = lane >> 1, block = lane & 1)
+    const int wrl = lane >> 2, wp = (lane & 3) ^ ((wrl >> 2) & 3);
+    const uint8_t *wsrc = W + (int64_t)(row0 + wrl < M ? row0 + wrl : M - 1) * (int64_t)(K >> 1);
+    const int srl = (lane >> 1) & 15;
+    const float *ssrc = absmax + (int64_t)(row0 + srl < M ? row0 + srl : M - 1) * nblk;
+
+    const int xrd0 = i * 128 + (((2 * kb) ^ (i >> 1)) * 16), xrd1 = i * 128 + (((2 * kb + 1) ^ (i >> 1)) * 16);
+
+    f32x4 acc[1][NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[0][nt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+    constexpr int kGroup = 4 * NT + 2;
+    auto issue = [&](int t) {
+        const int jb0 = (t * WK + wk) * 2, left = nblk - jb0;  // blocks of this wave's pair that exist: <= 0, 1 or >= 2 (wave-uniform)
+        if (left <= 0) return;
+        uint8_t *slot = mine + (t % D) * kWaveSlot;
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+            if (b < left) {
+#pragma unroll
+                for (int d = 0; d < 2 * NT; ++d) lds_dma16(xb + xoff[d] + (uint32_t)(jb0 + b) * 128u, slot + b * (NT * 2048) + d * 1024);
+            }
+        lds_dma16(wsrc + jb0 * 32 + ((wp >> 1) < left ? wp * 16 : (wp & 1) * 16), slot + kXSlot);
+        if (lane < 32)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ssrc + jb0 + ((lane & 1) < left ? (lane & 1) : 0)),
+                                             (__attribute__((address_space(3))) void *)(slot + kXSlot + 1024), 4, 0, 0);
+    };
+    for (int t = 0; t < D - 1 && t < steps; ++t) issue(t);
+    for (int t = 0; t < steps; ++t) {
+        // this wave's step t has landed; D - 2 younger steps may stay in flight (not near the end, where groups may be smaller)
+        if (D > 2 && t + D - 2 < steps - 1)
+            wait_vmcnt<(D - 2) * kGroup>();
+        else
+            wait_vmcnt<0>();
+        asm volatile("" ::: "memory");
+        if (t + D - 1 < steps) issue(t + D - 1);  // into the slot step t - 1 used (its reads have been consumed)
+        const int left = nblk - (t * WK + wk) * 2;
+        const uint8_t *slot = mine + (t % D) * kWaveSlot;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            if (b >= left) break;  // wave-uniform (ragged end)
+            const u32x2 wq = *reinterpret_cast<const u32x2 *>(slot + kXSlot + i * 64 + (((2 * b + (kb >> 1)) ^ ((i >> 2) & 3)) * 16) + (kb & 1) * 8);
+            const float am = *reinterpret_cast<const float *>(slot + kXSlot + 1024 + i * 8 + b * 4);
+            const uint8_t *xs = slot + b * (NT * 2048);
+            f32x4 tile[NT];
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2) {
+                const u32x4 wf = decode8_natural<DT>(t2 == 0 ? wq.x : wq.y);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const u32x4 xf = *reinterpret_cast<const u32x4 *>(xs + nt * 2048 + (t2 == 0 ? xrd0 : xrd1));
+                    tile[nt] = mfma_xw<DT>(xf, wf, t2 == 0 ? f32x4{0.0f, 0.0f, 0.0f, 0.0f} : tile[nt]);
+                }
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                acc[0][nt].x = __builtin_fmaf(tile[nt].x, am, acc[0][nt].x);
+                acc[0][nt].y = __builtin_fmaf(tile[nt].y, am, acc[0][nt].y);
+                acc[0][nt].z = __builtin_fmaf(tile[nt].z, am, acc[0][nt].z);
+                acc[0][nt].w = __builtin_fmaf(tile[nt].w, am, acc[0][nt].w);
+            }
+        }
+    }
+    __syncthreads();  // every wave is done with its ring before the partials overwrite the storage
+    wide_epilogue<DT, NT, 1, 1>(s_raw, acc, bias, residual, out, B, M, row0, mode);
+}
+
+std::atomic<int> g_wide_cfg{-1};  // -1 heuristic; 0 = never (16-row launches); 1 / 2 / 3 / 4 = 16 / 32 / 64 / 128 rows per workgroup;
+                                  // 5 = 16 rows, self-contained waves (up to 32 activation rows, else as 1)
 
 template <int DT, int NT>
 int dispatch_wide_cfg(int cfg, const void *x, const uint8_t *W, const float *absmax, const void *bias, const void *residual, void *out,
                       int B, int M, int K, int mode, hipStream_t stream) {
-    const unsigned rows = cfg == 1 ? 16u : (cfg == 2 ? 32u : (cfg == 3 ? 64u : 128u));
+    const unsigned rows = (cfg == 1 || cfg == 5) ? 16u : (cfg == 2 ? 32u : (cfg == 3 ? 64u : 128u));
     const dim3 grid(((unsigned)M + rows - 1) / rows);
 #define FP4_WIDE_ARGS reinterpret_cast<const uint16_t *>(x), W, absmax, reinterpret_cast<const uint16_t *>(bias), \
                       reinterpret_cast<const uint16_t *>(residual), reinterpret_cast<uint16_t *>(out), B, M, K, mode
+    if (cfg == 5) {
+        if constexpr (NT <= 2) {
+            hipLaunchKernelGGL((gemm16_wide_auto_kernel<DT, NT>), dim3(((unsigned)M + 15u) / 16u), dim3(512), 0, stream, FP4_WIDE_ARGS);
+            return FP4_OK;
+        }
+        cfg = 1;
+    }
     if (cfg == 1)
         hipLaunchKernelGGL((gemm16_wide_ring8_kernel<DT, NT>), grid, dim3(640), 0, stream, FP4_WIDE_ARGS);
     else if (cfg == 2)
@@ -417,7 +524,7 @@ int dispatch_wide(int cfg, const void *x, const uint8_t *W, const float *absmax,
 
 }  // namespace
 
-void set_wide_variant(int v) { g_wide_cfg = v < 0 ? -1 : (v > 4 ? 4 : v); }
+void set_wide_variant(int v) { g_wide_cfg = v < 0 ? -1 : (v > 5 ? 5 : v); }
 
 // 17..64 activation rows (any_rows: 1..64 - the caller's other kernels do not cover the shape), 16-bit dtype, blocksize 64,
 // K % 64 == 0, 16-byte aligned operands.  Returns FP4_OK after the launch, or -1 when the shape is not covered / the path is switched
@@ -435,6 +542,7 @@ int gemm_wide_launch(int dtype, const void *x, const uint8_t *W, const float *ab
             cfg = M >= 48 * cus ? 3 : (M >= 20 * cus ? 2 : 1);
         else
             cfg = M >= 96 * cus ? 4 : (M >= 48 * cus ? 3 : (M >= 24 * cus ? 2 : 1));
+        if (cfg == 1 && B <= 32) cfg = 5;  // 16 rows per workgroup, one or two column tiles: the barrier-free form (5-17 % faster)
     }
     return dtype == FP4_DTYPE_F16 ? dispatch_wide<FP4_DTYPE_F16>(cfg, x, W, absmax, bias, residual, out, B, M, K, mode, stream)
                                   : dispatch_wide<FP4_DTYPE_BF16>(cfg, x, W, absmax, bias, residual, out, B, M, K, mode, stream);
