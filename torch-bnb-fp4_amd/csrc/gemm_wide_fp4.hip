@@ -10,8 +10,8 @@
 //     on-chip stream - goes into LDS in full 128-byte lines by LDS-DMA (global_load_lds_dwordx4, no VGPR staging), 2..4 ring
 //     slots per K slice; the image is lane-linear, so the bank swizzle (16-byte unit ^ (column >> 1)) is applied to the SOURCE
 //     address and again to the ds_read_b128 address;
-//   * the weight and its block scales come by LDS-DMA as well, in full lines, into a ring several steps deep (see the two kernels
-//     for who issues what); a first version loaded them fragment-shaped into registers one step ahead and spent more time on that
+//   * the weight and its block scales come by LDS-DMA as well, in full lines, into a ring several steps deep (see the three
+//     kernels for who issues what); a first version loaded them fragment-shaped into registers one step ahead and spent more time on that
 //     than on everything else (profiles/r02_wide_batch_17_to_128_rows.txt);
 //   * waits are counted (s_waitcnt vmcnt(N) in front of a bare s_barrier), so younger steps stay in flight across the barrier;
 //   * x is the A operand and the weight the B operand, so a lane's accumulators all belong to ONE weight row and the block scale is
