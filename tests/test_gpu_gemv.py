@@ -234,7 +234,7 @@ def test_partial_f32_output_and_k_split_sum(dtype):
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("kernel", [-1, 0, 1 | (1 << 4), 1 | (2 << 4), 1 | (1 << 4) | (1 << 8), 1 | (2 << 4) | (1 << 8), 1 | (1 << 4) | (2 << 14)])  # VALU kernel; matrix-core kernel: 1 / 2 row tiles, LDS-staged / direct weight loads, 8 blocks per pass wherever they divide K
-@pytest.mark.parametrize("B", [1, 2, 3, 4, 5, 8, 9, 13, 16])
+@pytest.mark.parametrize("B", [1, 2, 4, 5, 8, 9, 13, 16])
 @pytest.mark.parametrize("M,K", [(4096, 4096), (1024, 4096), (2048, 768), (66, 2048), (257, 1024), (300, 8192), (40, 14336), (33, 512),
                                  (130, 11008), (48, 1472), (70, 5120), (36, 13824)])
 def test_small_batch_fused_gemm(dtype, kernel, B, M, K):
@@ -343,7 +343,7 @@ def wide_case(M, K):
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5])  # 16 / 32 / 64 / 128 rows per workgroup; 5: the barrier-free 16-row kernel (up to 32 rows)
-@pytest.mark.parametrize("B", [17, 24, 32, 33, 40, 48, 49, 64])
+@pytest.mark.parametrize("B", [17, 32, 33, 48, 49, 64])
 @pytest.mark.parametrize("M,K", WIDE_SHAPES)
 def test_wide_batch_one_pass_kernel(dtype, cfg, B, M, K):
     """17..64 activation rows in ONE pass over the weight (gemm16_wide_ring8_kernel / gemm16_wide_ring_kernel: every stream through
