@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FP4_HIP_ABI_VERSION 5
+#define FP4_HIP_ABI_VERSION 6
 #define FP4_HIP_API __attribute__((visibility("default")))
 
 /* Element types, numbered like the reference's ScalarTypeEnum (csrc/torch_fp4.cpp:22-26). */
@@ -139,6 +139,19 @@ FP4_HIP_API int fp4_hip_gemm_small(const void *x, const uint8_t *packed, const f
 FP4_HIP_API int fp4_hip_gemm_small_fused(const void *x, const uint8_t *packed, const float *absmax, const void *bias,
                              const void *residual, void *out, int64_t B, int64_t M, int64_t K, int blocksize, int dtype,
                              int epilogue, void *stream);
+
+/*
+ * fp4_hip_gemm_small_fused with a caller-provided scratch buffer.  On short weights with long rows (M below 24 rows per CU, K >= 8192:
+ * the down projection of a decoder) 33..64 activation rows run as x-stationary split-K over workgroups: partial sums of 512-column
+ * slices go through `workspace` and a second small launch adds them in a fixed order and applies the epilogue (deterministic, no
+ * atomics).  fp4_hip_gemm_small_ws_bytes returns the bytes that path wants for a shape, or 0 where it would not be used (then, or
+ * with workspace == NULL or too small, the call is exactly fp4_hip_gemm_small_fused).  16-byte aligned workspace; it may be reused by
+ * the next call on the same stream.  Not in the reference.
+ */
+FP4_HIP_API int64_t fp4_hip_gemm_small_ws_bytes(int64_t B, int64_t M, int64_t K, int blocksize, int dtype);
+FP4_HIP_API int fp4_hip_gemm_small_ws(const void *x, const uint8_t *packed, const float *absmax, const void *bias, const void *residual,
+                          void *out, int64_t B, int64_t M, int64_t K, int blocksize, int dtype, int epilogue, void *workspace,
+                          int64_t workspace_bytes, void *stream);
 
 /*
  * K-split (row-parallel) building block: the same GEMV, but the f32 accumulator is written as is

@@ -114,6 +114,26 @@ def gemm_small(x: torch.Tensor, packed: torch.Tensor, absmax: torch.Tensor, M: i
     return rc
 
 
+def gemm_small_ws(x: torch.Tensor, packed: torch.Tensor, absmax: torch.Tensor, M: int, K: int, blocksize: int,
+                  bias: torch.Tensor | None = None, residual: torch.Tensor | None = None, epilogue: int = EPILOGUE_NONE,
+                  workspace: torch.Tensor | None = None):
+    """fp4_hip_gemm_small_ws with a workspace of the size the library asks for (or the one given); returns (out, bytes asked)."""
+    B = x.numel() // K
+    l = lib()
+    l.fp4_hip_gemm_small_ws_bytes.restype = ctypes.c_int64
+    l.fp4_hip_gemm_small_ws_bytes.argtypes = [ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_int]
+    want = l.fp4_hip_gemm_small_ws_bytes(B, M, K, blocksize, DT[x.dtype])
+    if workspace is None and want > 0:
+        workspace = torch.empty(want, dtype=torch.uint8, device=x.device)
+    out = torch.empty(B, M // 2 if epilogue == EPILOGUE_SILU_MUL_PAIRS else M, dtype=x.dtype, device=x.device)
+    vp, i64, i32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int
+    l.fp4_hip_gemm_small_ws.argtypes = [vp, vp, vp, vp, vp, vp, i64, i64, i64, i32, i32, i32, vp, i64, vp]
+    rc = l.fp4_hip_gemm_small_ws(_ptr(x), _ptr(packed), _ptr(absmax), _ptr(bias), _ptr(residual), _ptr(out), B, M, K, blocksize, DT[x.dtype],
+                                 epilogue, _ptr(workspace), 0 if workspace is None else workspace.numel(), _stream())
+    assert rc == OK, (rc, last_error())
+    return out, want
+
+
 def gemm_small_fused(x: torch.Tensor, packed: torch.Tensor, absmax: torch.Tensor, M: int, K: int, blocksize: int,
                      bias: torch.Tensor | None = None, residual: torch.Tensor | None = None, epilogue: int = EPILOGUE_NONE,
                      expect_ok: bool = True):

@@ -372,6 +372,49 @@ def test_wide_batch_one_pass_kernel(dtype, cfg, B, M, K):
     assert (err <= HALF_ULP[dtype] * 1.01 * np.abs(exact) + 1e-5 * scale + 1e-30).all(), float(err.max())
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B", [2, 5, 16, 17, 33, 48, 64])
+@pytest.mark.parametrize("M,K", [(4096, 14336), (4096, 11008), (300, 8192), (130, 13824), (2050, 8256), (16, 8192)])
+def test_split_k_with_workspace(dtype, B, M, K):
+    """fp4_hip_gemm_small_ws on and around the shapes its split-K path takes (33..64 rows, short weight, K >= 8192; ragged last K slice
+    at 11008 and 8256, ragged rows, more tiles than waves and fewer): partial sums through the workspace + the reducing launch meet the GEMV bar
+    against the float64 product; twice the same call gives the same bits (fixed summation order); without a workspace, or with one
+    that is too small, the call is fp4_hip_gemm_small_fused and agrees with it bit for bit."""
+    packed, am, w = wide_case(M, K) if (M, K) in WIDE_SHAPES else (None, None, None)
+    if packed is None:
+        packed, am, _ = make_case(M, K, seed=77 + M)
+        w = o.dequantize_f32(packed, am, 64, M * K).reshape(M, K).astype(np.float64)
+    rng = np.random.default_rng(B * 13 + K)
+    x_t = torch_values(rng.standard_normal((B, K)).astype(np.float32), dtype)
+    b_t = torch_values(rng.standard_normal(M).astype(np.float32) * 0.1, dtype)
+    P, A = to_dev(packed), to_dev(am)
+    y, want_bytes = hipabi.gemm_small_ws(x_t, P, A, M, K, 64, bias=b_t)
+    assert want_bytes == (-(-(K // 64) // 8) * B * M * 4 if (B >= 33 and 16 <= M < 6144) else 0)  # (256 CUs: short = M < 6144)
+    xv = x_t.float().cpu().numpy().astype(np.float64)
+    bv = b_t.float().cpu().numpy().astype(np.float64)
+    exact = xv @ w.T + bv
+    scale = np.abs(xv) @ np.abs(w).T + np.abs(bv)
+    err = np.abs(y.float().cpu().numpy().astype(np.float64) - exact)
+    assert (err <= HALF_ULP[dtype] * 1.01 * np.abs(exact) + 1e-5 * scale + 1e-30).all(), float(err.max())
+    y2, _ = hipabi.gemm_small_ws(x_t, P, A, M, K, 64, bias=b_t)
+    assert torch.equal(y, y2)
+    small = torch.empty(max(16, want_bytes // 2), dtype=torch.uint8, device=dev())
+    y3, _ = hipabi.gemm_small_ws(x_t, P, A, M, K, 64, bias=b_t, workspace=small)
+    assert torch.equal(y3, hipabi.gemm_small_fused(x_t, P, A, M, K, 64, b_t, None))
+    if want_bytes == 0:
+        assert torch.equal(y, y3)  # not a split-K shape: the workspace entry IS the plain one
+    # epilogues through the reducing launch: residual bit-exact on top of the plain result, gate|up within one ulp of torch's ops
+    r_t = torch_values(rng.standard_normal((B, M)).astype(np.float32), dtype)
+    yr, _ = hipabi.gemm_small_ws(x_t, P, A, M, K, 64, bias=b_t, residual=r_t)
+    want = o.linear_epilogue(y.float().cpu().numpy(), "float16" if dtype == torch.float16 else "bfloat16", None, r_t.float().cpu().numpy())
+    assert np.array_equal(yr.float().cpu().numpy().view(np.uint32), np.asarray(want, np.float32).view(np.uint32))
+    if M % 2 == 0:
+        gu, _ = hipabi.gemm_small_ws(x_t, P, A, M, K, 64, bias=b_t, epilogue=hipabi.EPILOGUE_SILU_MUL_PAIRS)
+        ref = torch.nn.functional.silu(y[:, 0::2]) * y[:, 1::2]
+        d = (gu.view(torch.int16).int() - ref.view(torch.int16).int()).abs()
+        assert int(d.max()) <= 1 and float((d == 0).float().mean()) >= 0.995
+
+
 def test_small_batch_random_shapes_against_float64():
     """200 seeded random cases through fp4_hip_gemm_small: 1..128 rows, M in 1..200, K = 64 * (1..40) - fewer quant blocks than K
     slices, ragged last steps, single-row weights, every workgroup shape of the one-pass kernels forced or chosen - against the

@@ -46,7 +46,7 @@ for M, K in shapes:
     x1 = torch.randn(K, device=dev).to(torch.bfloat16)
     t_gemv = timeit(capture(lambda: [hipabi.gemv(x1, packed[i], absmax[i], M, K, 64) for i in range(R)]), R)
     print(f"{M}x{K} bf16 (R={R}): batch-1 gemv {t_gemv:.2f} us", flush=True)
-    for B in (8, 16, 24, 32, 48, 64, 96, 128):
+    for B in (2, 8, 16, 24, 32, 48, 64, 96, 128):
         x = torch.randn(B, K, device=dev).to(torch.bfloat16)
         t_small, t_cfg = None, {}
         if B <= 128:
@@ -63,8 +63,12 @@ for M, K in shapes:
                 hipabi.dequantize(packed[i], absmax[i], 64, n, torch.bfloat16, out=w.view(-1))
                 torch.nn.functional.linear(x, w)
         t_ref = timeit(capture(ref), R)
+        t_ws = None
+        if B <= 64:
+            ws = torch.empty(max(16, -(-(K // 64) // 8) * B * M * 4), dtype=torch.uint8, device=dev)
+            t_ws = timeit(capture(lambda: [hipabi.gemm_small_ws(x, packed[i], absmax[i], M, K, 64, workspace=ws) for i in range(R)]), R)
         s = f"{t_small:7.2f} us" if t_small is not None else "      - "
-        print(f"   rows {B:3d}: gemm_small {s}   dequant + hipBLASLt {t_ref:7.2f} us" + (f"   ratio {t_ref / t_small:4.2f}x" if t_small else "")
+        print(f"   rows {B:3d}: gemm_small {s}   dequant + hipBLASLt {t_ref:7.2f} us" + (f"   ratio {t_ref / t_small:4.2f}x" if t_small else "") + (f"   with workspace {t_ws:7.2f} us" if t_ws else "")
               + ("   [16-row launches / one pass with 16 / 32 / 64 rows per workgroup: " + " ".join(f"{t_cfg[c]:.2f}" for c in sorted(t_cfg)) + "]" if t_cfg else ""), flush=True)
     del packed, absmax, wbuf
     torch.cuda.empty_cache()

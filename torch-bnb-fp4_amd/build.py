@@ -25,7 +25,7 @@ HIP_LIB = os.path.join(LIB_DIR, "libtorch_bnb_fp4_hip.so")
 EXT_LIB = os.path.join(HERE, "torch_bnb_fp4_ext.so")
 OBJ_DIR = os.path.join(REPO, "build_tmp", "obj")
 
-HIP_SOURCES = ["capi.hip", "dequant_fp4.hip", "gemv_fp4.hip", "gemm_small_fp4.hip", "gemm_wide_fp4.hip", "quantize_fp4.hip", "allreduce_oneshot.hip"]
+HIP_SOURCES = ["capi.hip", "dequant_fp4.hip", "gemv_fp4.hip", "gemm_small_fp4.hip", "gemm_wide_fp4.hip", "gemm_splitk_fp4.hip", "quantize_fp4.hip", "allreduce_oneshot.hip"]
 HIP_HEADERS = ["fp4_common.h", "gemv_common.h", os.path.join(INCLUDE, "torch_bnb_fp4_hip.h")]
 ARCH = "gfx950"
 # Kernel arguments are preloaded into SGPRs at wave launch instead of being fetched with s_load at the top of the

@@ -715,6 +715,9 @@ void set_small_variant(int v) {
 }  // namespace fp4
 
 namespace fp4 {
+int64_t gemm_splitk_workspace_bytes(int64_t B, int64_t M, int64_t K, int blocksize, int dtype);  // gemm_splitk_fp4.hip
+int gemm_splitk_launch(int dtype, const void *x, const uint8_t *W, const float *absmax, const void *bias, const void *residual, void *out,
+                       int B, int M, int K, int mode, void *workspace, int64_t workspace_bytes, hipStream_t stream);
 int gemm_wide_launch(int dtype, const void *x, const uint8_t *W, const float *absmax, const void *bias, const void *residual, void *out,
                      int B, int M, int K, int mode, bool any_rows, hipStream_t stream);  // gemm_wide_fp4.hip
 namespace {
@@ -816,4 +819,25 @@ extern "C" int fp4_hip_gemm_small_fused(const void *x, const uint8_t *packed, co
     }
     return fp4::gemm_small_entry(x, packed, absmax, bias, residual, out, B, M, K, blocksize, dtype,
                                  epilogue == FP4_EPILOGUE_SILU_MUL_PAIRS ? fp4::kModeSiluMulPairs : 0, stream);
+}
+
+extern "C" int64_t fp4_hip_gemm_small_ws_bytes(int64_t B, int64_t M, int64_t K, int blocksize, int dtype) {
+    return fp4::gemm_splitk_workspace_bytes(B, M, K, blocksize, dtype);
+}
+
+extern "C" int fp4_hip_gemm_small_ws(const void *x, const uint8_t *packed, const float *absmax, const void *bias, const void *residual,
+                                     void *out, int64_t B, int64_t M, int64_t K, int blocksize, int dtype, int epilogue, void *workspace,
+                                     int64_t workspace_bytes, void *stream) {
+    if (epilogue != FP4_EPILOGUE_NONE && epilogue != FP4_EPILOGUE_SILU_MUL_PAIRS) {
+        fp4::set_error("fp4_hip_gemm_small_ws: unknown epilogue %d", epilogue);
+        return FP4_ERR_INVALID_ARGUMENT;
+    }
+    const int mode = epilogue == FP4_EPILOGUE_SILU_MUL_PAIRS ? fp4::kModeSiluMulPairs : 0;
+    const uintptr_t al = reinterpret_cast<uintptr_t>(packed) | reinterpret_cast<uintptr_t>(x);
+    if (workspace && x && packed && absmax && out && (al & 15u) == 0 && B >= 33 && B <= 64 && M > 0 && M <= (int64_t(1) << 30) &&
+        K <= (int64_t(1) << 24) && !((mode & fp4::kModeSiluMulPairs) && (M & 1)) &&
+        fp4::gemm_splitk_launch(dtype, x, packed, absmax, bias, residual, out, (int)B, (int)M, (int)K, mode, workspace, workspace_bytes,
+                                static_cast<hipStream_t>(stream)) == FP4_OK)
+        return fp4::check_launch("fp4_hip_gemm_small_ws");
+    return fp4::gemm_small_entry(x, packed, absmax, bias, residual, out, B, M, K, blocksize, dtype, mode, stream);
 }

@@ -250,6 +250,14 @@ torch::Tensor gemm_small_fp4(torch::Tensor A, torch::Tensor B, torch::Tensor abs
         bias_ptr = bias_c.data_ptr();
     }
     c10::DeviceGuard guard(A.device());
+    // short weight x long rows: the split-K path wants a scratch buffer (torch's caching allocator: no sync, graph-capturable)
+    const int64_t ws_bytes = fp4_hip_gemm_small_ws_bytes(rows, m, k, blocksize, dt);
+    if (ws_bytes > 0) {
+        torch::Tensor ws = torch::empty({ws_bytes}, A.options().dtype(torch::kUInt8));
+        check_status(fp4_hip_gemm_small_ws(A.data_ptr(), B.data_ptr<uint8_t>(), absmax.data_ptr<float>(), bias_ptr, nullptr, out.data_ptr(),
+                                           rows, m, k, blocksize, dt, FP4_EPILOGUE_NONE, ws.data_ptr(), ws_bytes, current_stream(A)));
+        return out;
+    }
     check_status(fp4_hip_gemm_small(A.data_ptr(), B.data_ptr<uint8_t>(), absmax.data_ptr<float>(), bias_ptr, out.data_ptr(), rows, m,
                                     k, blocksize, dt, current_stream(A)));
     return out;
@@ -290,6 +298,13 @@ torch::Tensor gemm_small_fp4_fused(torch::Tensor A, torch::Tensor B, torch::Tens
         res_ptr = res_c.data_ptr();
     }
     c10::DeviceGuard guard(A.device());
+    const int64_t ws_bytes = fp4_hip_gemm_small_ws_bytes(rows, m, k, blocksize, dt);
+    if (ws_bytes > 0) {
+        torch::Tensor ws = torch::empty({ws_bytes}, A.options().dtype(torch::kUInt8));
+        check_status(fp4_hip_gemm_small_ws(A.data_ptr(), B.data_ptr<uint8_t>(), absmax.data_ptr<float>(), bias_ptr, res_ptr, out.data_ptr(),
+                                           rows, m, k, blocksize, dt, epilogue, ws.data_ptr(), ws_bytes, current_stream(A)));
+        return out;
+    }
     check_status(fp4_hip_gemm_small_fused(A.data_ptr(), B.data_ptr<uint8_t>(), absmax.data_ptr<float>(), bias_ptr, res_ptr, out.data_ptr(),
                                           rows, m, k, blocksize, dt, epilogue, current_stream(A)));
     return out;
