@@ -142,7 +142,7 @@ FP4_HIP_API int fp4_hip_gemm_small_fused(const void *x, const uint8_t *packed, c
 
 /*
  * fp4_hip_gemm_small_fused with a caller-provided scratch buffer.  On short weights with long rows (M below 24 rows per CU, K >= 8192:
- * the down projection of a decoder) 33..64 activation rows run as x-stationary split-K over workgroups: partial sums of 512-column
+ * the down projection of a decoder) 33..64 activation rows (65..128: two even chunks) run as x-stationary split-K over workgroups: partial sums of 512-column
  * slices go through `workspace` and a second small launch adds them in a fixed order and applies the epilogue (deterministic, no
  * atomics).  fp4_hip_gemm_small_ws_bytes returns the bytes that path wants for a shape, or 0 where it would not be used (then, or
  * with workspace == NULL or too small, the call is exactly fp4_hip_gemm_small_fused).  16-byte aligned workspace; it may be reused by

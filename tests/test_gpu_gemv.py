@@ -373,7 +373,7 @@ def test_wide_batch_one_pass_kernel(dtype, cfg, B, M, K):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("B", [2, 5, 16, 17, 33, 48, 64])
+@pytest.mark.parametrize("B", [2, 16, 33, 48, 64, 100])
 @pytest.mark.parametrize("M,K", [(4096, 14336), (4096, 11008), (300, 8192), (130, 13824), (2050, 8256), (16, 8192)])
 def test_split_k_with_workspace(dtype, B, M, K):
     """fp4_hip_gemm_small_ws on and around the shapes its split-K path takes (33..64 rows, short weight, K >= 8192; ragged last K slice
@@ -389,7 +389,8 @@ def test_split_k_with_workspace(dtype, B, M, K):
     b_t = torch_values(rng.standard_normal(M).astype(np.float32) * 0.1, dtype)
     P, A = to_dev(packed), to_dev(am)
     y, want_bytes = hipabi.gemm_small_ws(x_t, P, A, M, K, 64, bias=b_t)
-    assert want_bytes == (-(-(K // 64) // 8) * B * M * 4 if (B >= 33 and 16 <= M < 6144) else 0)  # (256 CUs: short = M < 6144)
+    chunk = B if B <= 64 else (B + 1) // 2  # 65..128 rows: two even chunks through the same workspace
+    assert want_bytes == (-(-(K // 64) // 8) * chunk * M * 4 if (chunk >= 33 and 16 <= M < 6144) else 0)  # (256 CUs: short = M < 6144)
     xv = x_t.float().cpu().numpy().astype(np.float64)
     bv = b_t.float().cpu().numpy().astype(np.float64)
     exact = xv @ w.T + bv

@@ -822,6 +822,7 @@ extern "C" int fp4_hip_gemm_small_fused(const void *x, const uint8_t *packed, co
 }
 
 extern "C" int64_t fp4_hip_gemm_small_ws_bytes(int64_t B, int64_t M, int64_t K, int blocksize, int dtype) {
+    if (B > 64 && B <= 128) B = (B + 1) / 2;  // two even chunks, one after the other through the same workspace
     return fp4::gemm_splitk_workspace_bytes(B, M, K, blocksize, dtype);
 }
 
@@ -833,6 +834,18 @@ extern "C" int fp4_hip_gemm_small_ws(const void *x, const uint8_t *packed, const
         return FP4_ERR_INVALID_ARGUMENT;
     }
     const int mode = epilogue == FP4_EPILOGUE_SILU_MUL_PAIRS ? fp4::kModeSiluMulPairs : 0;
+    if (B > 64 && B <= 128 && workspace && x && out && M > 0 && K > 0 && (dtype == FP4_DTYPE_F16 || dtype == FP4_DTYPE_BF16)) {
+        const int64_t M_out = (mode & fp4::kModeSiluMulPairs) ? M / 2 : M, per = (B + 1) / 2;
+        for (int64_t b0 = 0; b0 < B; b0 += per) {
+            const int64_t nb = B - b0 < per ? B - b0 : per;
+            const int rc = fp4_hip_gemm_small_ws(static_cast<const uint8_t *>(x) + size_t(b0) * size_t(K) * 2, packed, absmax, bias,
+                                                 residual ? static_cast<const uint8_t *>(residual) + size_t(b0) * size_t(M_out) * 2 : nullptr,
+                                                 static_cast<uint8_t *>(out) + size_t(b0) * size_t(M_out) * 2, nb, M, K, blocksize, dtype,
+                                                 epilogue, workspace, workspace_bytes, stream);
+            if (rc != FP4_OK) return rc;
+        }
+        return FP4_OK;
+    }
     const uintptr_t al = reinterpret_cast<uintptr_t>(packed) | reinterpret_cast<uintptr_t>(x);
     if (workspace && x && packed && absmax && out && (al & 15u) == 0 && B >= 33 && B <= 64 && M > 0 && M <= (int64_t(1) << 30) &&
         K <= (int64_t(1) << 24) && !((mode & fp4::kModeSiluMulPairs) && (M & 1)) &&
