@@ -126,36 +126,131 @@ def tp_ksplit_leg(lib, dist, backend, rank, world, dev, x, packed0, absmax0, bar
     return out
 
 
-def launch_workers(n, argv, script=None, timeout_s=None, out=None):
+STAGE_TAG = "@@fp4-bench"  # progress marker every rank writes to stdout: "@@fp4-bench rank=R stage=S"; the parent tracks it, never relays it
+STAGES = ("started", "process-group-ready", "buffers-ready", "timed-region-done", "done")
+
+
+def stage(name):
+    """Workers of an N > 1 run tell the launching parent how far they got (one short line per stage, flushed)."""
+    if _WATCHDOG is not None:
+        _WATCHDOG.stage = name
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        print(f"{STAGE_TAG} rank={os.environ.get('RANK', '0')} stage={name}", flush=True)
+
+
+class Watchdog:
+    """Every rank's own deadline (the driver starts the N > 1 ranks under torchrun itself, so the parent's deadline in
+    launch_workers is not there to help): when it passes, the rank says on stderr which stage it was in, rank 0 prints
+    the headline line if the timed region had already finished (marked "incomplete": the optional legs after it did
+    not), and the process leaves with code 124 - a reason and an exit, never a silent hang."""
+
+    def __init__(self, seconds, rank):
+        import threading
+
+        self.seconds, self.rank, self.stage, self.provisional = float(seconds), rank, "started", None
+        self._timer = threading.Timer(self.seconds, self._fire)
+        self._timer.daemon = True
+        self._timer.start()
+
+    def _fire(self):
+        print(f"bench.py: rank {self.rank}: deadline of {self.seconds:.0f} s passed in stage '{self.stage}'; giving up", file=sys.stderr, flush=True)
+        if self.provisional is not None:
+            line = dict(self.provisional)
+            line["incomplete"] = f"deadline of {self.seconds:.0f} s passed in stage '{self.stage}': figures after the timed region are missing"
+            print(json.dumps(line), flush=True)
+        os._exit(124)
+
+    def cancel(self):
+        self._timer.cancel()
+
+
+_WATCHDOG = None
+
+
+def _kill_group(proc, grace_s=5.0):
+    """End the worker group WE started (its own session / process group id == proc.pid): TERM, then KILL."""
+    import signal
+
+    for sig, wait_s in ((signal.SIGTERM, grace_s), (signal.SIGKILL, 10.0)):
+        try:
+            os.killpg(proc.pid, sig)
+        except (ProcessLookupError, PermissionError):
+            pass
+        try:
+            proc.wait(timeout=wait_s)
+            return
+        except subprocess.TimeoutExpired:
+            continue
+
+
+def launch_workers(n, argv, script=None, timeout_s=None, out=None, deadline_s=480.0):
     """`python bench.py --gpus N` without torchrun: start the N ranks as CHILD processes (never exec: a process that has
     touched the GPU must not be replaced, and this parent stays GPU-free so that it can relay), wait for them, print
-    rank 0's JSON line on our stdout and return the children's exit code (non-zero if any rank failed: no retry)."""
+    rank 0's JSON line on our stdout and return the children's exit code (non-zero if any rank failed: no retry).
+
+    The whole run has ONE deadline (`deadline_s`, `--deadline`; `timeout_s` is its older name): when it passes, the worker
+    group (a session of its own) is killed, the stage every rank last reported is printed - so a rank stuck in RCCL
+    initialisation reads "rank 5: never got past 'started'" instead of a silent driver kill - and the exit code is 124."""
+    import threading
+
+    if timeout_s is not None:
+        deadline_s = timeout_s
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["FP4_BENCH_DEADLINE_S"] = str(deadline_s)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), script or os.path.abspath(__file__), *argv]
     out = out or sys.stdout
-    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
-    line = None
-    try:
-        for raw in proc.stdout:  # rank 0 prints exactly one JSON line; anything else a child writes goes to stderr
+    t_start = time.monotonic()
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True, start_new_session=True)
+    state = {"line": None, "stages": {}}
+
+    def pump():  # rank 0 prints exactly one JSON line; stage markers are tracked; anything else a child writes goes to stderr
+        for raw in proc.stdout:
             txt = raw.strip()
-            if txt.startswith("{") and '"metric"' in txt:
-                line = txt
+            if txt.startswith(STAGE_TAG):
+                try:
+                    fields = dict(f.split("=", 1) for f in txt.split()[1:])
+                    state["stages"][int(fields["rank"])] = fields["stage"]
+                except (ValueError, KeyError):
+                    pass
+            elif txt.startswith("{") and '"metric"' in txt:
+                state["line"] = txt
             elif txt:
                 print(txt, file=sys.stderr, flush=True)
-        rc = proc.wait(timeout=timeout_s)
+
+    reader = threading.Thread(target=pump, daemon=True)
+    reader.start()
+    try:
+        rc = proc.wait(timeout=deadline_s)
+    except subprocess.TimeoutExpired:
+        _kill_group(proc)
+        reader.join(timeout=5.0)
+        print(f"bench.py: the {n}-rank worker group did not finish within the deadline of {deadline_s:.0f} s "
+              f"(ran {time.monotonic() - t_start:.0f} s); killed.  Last stage reported by each rank:", file=sys.stderr, flush=True)
+        for r in range(n):
+            last = state["stages"].get(r)
+            what = f"last stage '{last}'" if last else "no stage reported (never reached main(): import or launcher problem)"
+            if last == "started":
+                what += " - never finished process-group initialisation (RCCL / rendezvous)"
+            print(f"  rank {r}: {what}", file=sys.stderr, flush=True)
+        if state["line"] is None:
+            print("  no result line was produced", file=sys.stderr, flush=True)
+        return 124
     except BaseException:
-        proc.kill()
-        proc.wait()
+        _kill_group(proc)
         raise
+    reader.join(timeout=10.0)
+    line = state["line"]
     if line is not None:
         print(line, file=out, flush=True)
     if rc != 0:
-        print(f"bench.py: the {n}-rank worker group exited with code {rc}", file=sys.stderr, flush=True)
+        stuck = [f"rank {r}: '{state['stages'].get(r, 'nothing')}'" for r in range(n) if state["stages"].get(r) != "done"]
+        print(f"bench.py: the {n}-rank worker group exited with code {rc}" + (f" (did not finish: {', '.join(stuck)})" if stuck else ""),
+              file=sys.stderr, flush=True)
         return rc
     if line is None:
         print("bench.py: the worker group printed no result line", file=sys.stderr, flush=True)
@@ -306,11 +401,18 @@ def time_replays(replay, reps, launches):
 
 
 def committed_traffic(prefix: str):
-    """Per-launch HBM bytes of a kernel from the committed PMC profile (profiles/*traffic.json, produced by
-    tools/pmc_traffic.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this very script)."""
+    """Per-launch HBM bytes of a kernel from the committed PMC profile (profiles/rNN_traffic*.json, produced by
+    tools/pmc_traffic.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this very script): the
+    latest round's file, and within a round the one marked "final" if there is one."""
     import glob
+    import re
 
-    files = sorted(glob.glob(os.path.join(REPO, "profiles", "*traffic.json")))
+    def order(path):
+        name = os.path.basename(path)
+        m = re.match(r"r(\d+)_", name)
+        return (int(m.group(1)) if m else -1, "final" in name, name)
+
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_traffic*.json")), key=order)
     if not files:
         return None, None
     data = json.load(open(files[-1]))
@@ -381,6 +483,8 @@ def main():
     ap.add_argument("--matrices", type=int, default=64, help="distinct 4096x4096 FP4 weights per step (R)")
     ap.add_argument("--gemv-reps", type=int, default=4, help="GEMV passes over the R weights per step")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--deadline", type=float, default=480.0,
+                    help="N > 1 started without torchrun: seconds after which the worker group is killed and the run fails with a reason")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -388,7 +492,7 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: nothing below this line has touched the GPU yet (importing torch does not)
-        sys.exit(launch_workers(args.gpus, sys.argv[1:]))
+        sys.exit(launch_workers(args.gpus, sys.argv[1:], deadline_s=args.deadline))
     if args.gpus != world:
         sys.exit(f"--gpus {args.gpus} does not match WORLD_SIZE={world}")
     # one rank per GPU; FP4_BENCH_BACKEND=gloo lets the N > 1 code path be rehearsed on a box with fewer GPUs
@@ -400,14 +504,28 @@ def main():
     local_dev = local % max(1, ndev)
     torch.cuda.set_device(local_dev)
     dev = torch.device("cuda", local_dev)
+    global _WATCHDOG
+    # under our own parent the rank's deadline sits a little inside the parent's, so that the rank's reason is printed first
+    own = float(os.environ["FP4_BENCH_DEADLINE_S"]) - 15.0 if "FP4_BENCH_DEADLINE_S" in os.environ else args.deadline
+    _WATCHDOG = Watchdog(max(5.0, own), rank)
+    stage("started")
     if world > 1:
+        import datetime
+
         import torch.distributed as dist
 
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
+        # a rendezvous / RCCL initialisation that does not complete raises here with its reason (well inside the parent's deadline)
+        init_timeout = datetime.timedelta(seconds=max(30.0, min(180.0, float(os.environ.get("FP4_BENCH_DEADLINE_S", "480")) / 3)))
+        try:
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=dev, timeout=init_timeout)
+            else:
+                dist.init_process_group(backend, timeout=init_timeout)
+        except Exception as exc:
+            print(f"bench.py: rank {rank}: process-group initialisation ({backend}) failed: {type(exc).__name__}: {exc}", file=sys.stderr, flush=True)
+            raise
+    stage("process-group-ready")
 
     lib = Lib()
     R, GR = args.matrices, args.gemv_reps
@@ -432,6 +550,7 @@ def main():
 
         dq_replay = capture(dq_pass)
         gv_replay = capture(gv_pass)
+        stage("buffers-ready")
 
         def barrier():
             if world > 1:
@@ -455,6 +574,74 @@ def main():
         dq_ms = [e[0].elapsed_time(e[1]) for e in ev]
         gv_ms = [e[1].elapsed_time(e[2]) for e in ev]
         dq_total_s, gv_total_s = sum(dq_ms) / 1e3, sum(gv_ms) / 1e3
+
+        times = torch.tensor([wall, dq_total_s, gv_total_s], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        if world > 1:
+            dist.all_reduce(times, op=dist.ReduceOp.MAX)
+        wall, dq_total_s, gv_total_s = times.tolist()
+        line = None
+        if rank == 0:
+            dq_b, gv_b = dequant_bytes(M, K, BLOCKSIZE, 2), gemv_bytes(M, K, BLOCKSIZE, 2)
+            dq_launches, gv_launches = args.steps * R, args.steps * R * GR
+            dq_us, gv_us = dq_total_s * 1e6 / dq_launches, gv_total_s * 1e6 / gv_launches
+            dq_gbps_gpu = dq_b / dq_us / 1e3
+            gv_gbps_gpu = gv_b / gv_us / 1e3
+            line = {
+                "metric": "FP4 dequant GB/s (% HBM peak) + fused-GEMV us/layer, 4096x4096 bf16",
+                "value": round(dq_gbps_gpu * world, 1),
+                "unit": "GB/s",
+                "n_gpus": world,
+                "steps": args.steps,
+                "warmup": args.warmup,
+                "ms_per_step": round(wall * 1e3 / args.steps, 4),
+                "higher_is_better": True,
+                "scaling": "weak",
+                "vs_baseline": None,
+                "dtype": "bf16",
+                "data": "synthetic",
+                "config": {
+                    "workload": f"FP4 4096x4096 blocksize 64 -> bf16: per step {R} distinct weights, each dequantised once and "
+                                f"GEMV'd {GR}x (batch 1), HBM-cold rotation over {R * (dq_b) / 1e9:.2f} GB, HIP-graph replay",
+                    "M": M, "K": K, "blocksize": BLOCKSIZE, "matrices_per_step": R, "gemv_passes_per_step": GR,
+                    "parallelism": f"independent row shards x{world}, no collective",
+                },
+                "pct_hbm_peak": round(100 * dq_gbps_gpu / HBM_PEAK_GBPS, 2),
+                "dequant_us_per_matrix": round(dq_us, 3),
+                "gemv_us_per_layer": round(gv_us, 3),
+                "gemv_gbps": round(gv_gbps_gpu * world, 1),
+                "gemv_pct_hbm_peak": round(100 * gv_gbps_gpu / HBM_PEAK_GBPS, 2),
+                "roofline": {
+                    "bound": "hbm",
+                    "kernel": "dequant_tiles_kernel<bf16> (fp4_hip_dequantize_blockwise)",
+                    "achieved": round(dq_gbps_gpu, 1),
+                    "peak": HBM_PEAK_GBPS,
+                    "unit": "GB/s",
+                    "frac": round(dq_gbps_gpu / HBM_PEAK_GBPS, 4),
+                    "traffic": None,
+                    "bytes_per_launch": dq_b,
+                    "avg_launch_us": round(dq_us, 3),
+                    "method": "HIP events around each graph replay of R back-to-back launches on the launch stream; includes one kernel "
+                              "boundary per launch; rocprofv3 trace of this command: profiles/r02_h_bench_kernel_trace_summary.json",
+                },
+                "roofline_gemv": {
+                    "bound": "hbm", "kernel": "gemv16_regx_kernel<bf16> (fp4_hip_gemv)", "achieved": round(gv_gbps_gpu, 1),
+                    "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(gv_gbps_gpu / HBM_PEAK_GBPS, 4), "traffic": None,
+                    "bytes_per_launch": gv_b, "avg_launch_us": round(gv_us, 3),
+                },
+            }
+            for key, prefix in (("roofline", "dequant_tiles_kernel<2,"), ("roofline_gemv", "gemv16_regx_kernel<2,")):
+                traffic, src = committed_traffic(prefix)
+                line[key]["traffic"] = traffic
+                line[key]["traffic_source"] = src
+            def spread(ms, launches):  # median and inter-quartile range over the timed steps, us per launch (rank 0)
+                us = sorted(v * 1e3 / launches for v in ms)
+                q = statistics.quantiles(us, n=4) if len(us) >= 4 else [us[0], us[len(us) // 2], us[-1]]
+                return {"median_us": round(q[1], 3), "iqr_us": round(q[2] - q[0], 3), "min_us": round(us[0], 3), "max_us": round(us[-1], 3)}
+
+            line["dequant_step_spread"] = spread(dq_ms, R)
+            line["gemv_step_spread"] = spread(gv_ms, R * GR)
+            _WATCHDOG.provisional = line
+        stage("timed-region-done")
 
         # ---- secondary figures (outside the timed region) ------------------------------------
         extra = {}
@@ -564,71 +751,7 @@ def main():
                 except Exception as exc:
                     extra["c4_mistral7b_decode"] = {"error": repr(exc)[:300]}
 
-    times = torch.tensor([wall, dq_total_s, gv_total_s], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-    if world > 1:
-        dist.all_reduce(times, op=dist.ReduceOp.MAX)
-    wall, dq_total_s, gv_total_s = times.tolist()
-
     if rank == 0:
-        dq_b, gv_b = dequant_bytes(M, K, BLOCKSIZE, 2), gemv_bytes(M, K, BLOCKSIZE, 2)
-        dq_launches, gv_launches = args.steps * R, args.steps * R * GR
-        dq_us, gv_us = dq_total_s * 1e6 / dq_launches, gv_total_s * 1e6 / gv_launches
-        dq_gbps_gpu = dq_b / dq_us / 1e3
-        gv_gbps_gpu = gv_b / gv_us / 1e3
-        line = {
-            "metric": "FP4 dequant GB/s (% HBM peak) + fused-GEMV us/layer, 4096x4096 bf16",
-            "value": round(dq_gbps_gpu * world, 1),
-            "unit": "GB/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": round(wall * 1e3 / args.steps, 4),
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "bf16",
-            "data": "synthetic",
-            "config": {
-                "workload": f"FP4 4096x4096 blocksize 64 -> bf16: per step {R} distinct weights, each dequantised once and "
-                            f"GEMV'd {GR}x (batch 1), HBM-cold rotation over {R * (dq_b) / 1e9:.2f} GB, HIP-graph replay",
-                "M": M, "K": K, "blocksize": BLOCKSIZE, "matrices_per_step": R, "gemv_passes_per_step": GR,
-                "parallelism": f"independent row shards x{world}, no collective",
-            },
-            "pct_hbm_peak": round(100 * dq_gbps_gpu / HBM_PEAK_GBPS, 2),
-            "dequant_us_per_matrix": round(dq_us, 3),
-            "gemv_us_per_layer": round(gv_us, 3),
-            "gemv_gbps": round(gv_gbps_gpu * world, 1),
-            "gemv_pct_hbm_peak": round(100 * gv_gbps_gpu / HBM_PEAK_GBPS, 2),
-            "roofline": {
-                "bound": "hbm",
-                "kernel": "dequant_tiles_kernel<bf16> (fp4_hip_dequantize_blockwise)",
-                "achieved": round(dq_gbps_gpu, 1),
-                "peak": HBM_PEAK_GBPS,
-                "unit": "GB/s",
-                "frac": round(dq_gbps_gpu / HBM_PEAK_GBPS, 4),
-                "traffic": None,
-                "bytes_per_launch": dq_b,
-                "avg_launch_us": round(dq_us, 3),
-                "method": "HIP events around each graph replay of R back-to-back launches on the launch stream; includes one kernel "
-                          "boundary per launch; rocprofv3 trace of this command: profiles/r02_h_bench_kernel_trace_summary.json",
-            },
-            "roofline_gemv": {
-                "bound": "hbm", "kernel": "gemv16_regx_kernel<bf16> (fp4_hip_gemv)", "achieved": round(gv_gbps_gpu, 1),
-                "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(gv_gbps_gpu / HBM_PEAK_GBPS, 4), "traffic": None,
-                "bytes_per_launch": gv_b, "avg_launch_us": round(gv_us, 3),
-            },
-        }
-        for key, prefix in (("roofline", "dequant_tiles_kernel<2,"), ("roofline_gemv", "gemv16_regx_kernel<2,")):
-            traffic, src = committed_traffic(prefix)
-            line[key]["traffic"] = traffic
-            line[key]["traffic_source"] = src
-        def spread(ms, launches):  # median and inter-quartile range over the timed steps, us per launch (rank 0)
-            us = sorted(v * 1e3 / launches for v in ms)
-            q = statistics.quantiles(us, n=4) if len(us) >= 4 else [us[0], us[len(us) // 2], us[-1]]
-            return {"median_us": round(q[1], 3), "iqr_us": round(q[2] - q[0], 3), "min_us": round(us[0], 3), "max_us": round(us[-1], 3)}
-
-        line["dequant_step_spread"] = spread(dq_ms, R)
-        line["gemv_step_spread"] = spread(gv_ms, R * GR)
         line.update(extra)
         # the same kernels away from the launch boundary (one launch over a stack of R weights): what the kernel itself streams at
         if "dequant_stack_of_R_one_launch_gbps" in extra:
@@ -640,10 +763,13 @@ def main():
             line["fused_gemv_speedup_vs_dequant_hipblaslt"] = round(extra["dequant_plus_hipblaslt_gemv_us"] / gv_us, 2)
         if world == 1 and not args.no_cpu:
             line["cpu_baseline"] = cpu_baseline()
+        _WATCHDOG.provisional = None
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    stage("done")
+    _WATCHDOG.cancel()
 
 
 if __name__ == "__main__":

@@ -58,3 +58,52 @@ def test_plain_invocation_with_gpus_gt_1_spawns_before_any_gpu_call():
     main = src[src.index("def main():"):]
     assert main.index("launch_workers(args.gpus") < main.index("torch.cuda.")
     assert "os.exec" not in src
+
+
+def test_a_worker_group_that_outlives_the_deadline_is_killed_with_a_reason(tmp_path, capfd):
+    """A rank that never returns (a stuck RCCL initialisation on the 8-GPU box, say) must end in a non-zero exit inside the
+    deadline with the stage each rank had reached on stderr - not in a silent hang that the driver has to kill."""
+    import time
+
+    import bench
+
+    sleeper = _script(tmp_path, """
+        import os, sys, time
+        rank = os.environ["RANK"]
+        print(f"@@fp4-bench rank={rank} stage=started", flush=True)
+        if rank == "0":
+            print(f"@@fp4-bench rank={rank} stage=process-group-ready", flush=True)
+        time.sleep(600)
+    """)
+    out = io.StringIO()
+    t0 = time.monotonic()
+    rc = bench.launch_workers(2, [], script=sleeper, deadline_s=20, out=out)
+    took = time.monotonic() - t0
+    err = capfd.readouterr().err
+    assert rc == 124 and took < 60, (rc, took)
+    assert out.getvalue() == ""
+    assert "did not finish within the deadline" in err
+    assert "rank 0: last stage 'process-group-ready'" in err
+    assert "rank 1: last stage 'started'" in err and "never finished process-group initialisation" in err
+
+
+def test_the_rank_side_watchdog_prints_the_finished_headline_and_leaves(tmp_path):
+    """Under torchrun (how the driver starts N > 1) there is no parent of ours: every rank carries its own deadline.  If it
+    passes after the timed region, rank 0 still prints the headline line, marked incomplete, and the exit code is 124."""
+    import subprocess
+
+    worker = _script(tmp_path, f"""
+        import sys, time
+        sys.path.insert(0, {REPO!r})
+        import bench
+        w = bench.Watchdog(2.0, 0)
+        bench._WATCHDOG = w
+        bench.stage("timed-region-done")
+        w.provisional = {{"metric": "stand-in", "value": 1.0}}
+        time.sleep(120)
+    """)
+    p = subprocess.run([sys.executable, worker], capture_output=True, text=True, timeout=100)
+    assert p.returncode == 124
+    rec = json.loads(p.stdout.strip().splitlines()[-1])
+    assert rec["value"] == 1.0 and "timed-region-done" in rec["incomplete"]
+    assert "deadline of 2 s passed in stage 'timed-region-done'" in p.stderr

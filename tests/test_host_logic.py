@@ -269,3 +269,41 @@ def test_bnb_state_keys_match_the_installed_transformers_loader():
     assert meta == {"quant_type": "fp4", "blocksize": 64, "dtype": "float16", "shape": [64, 128]}
     assert state[prefix + "weight"].dtype == torch.uint8 and tuple(state[prefix + "weight"].shape) == (64 * 128 // 2, 1)
     assert state[prefix + "weight.absmax"].dtype == torch.float32 and state[prefix + "weight.quant_map"].numel() == 16
+
+
+def test_fused_layer_dtype_casts_never_touch_the_scales(fake, monkeypatch):
+    """model.half() / .to(torch.bfloat16) / .to(device, dtype) on a model holding FusedFP4Linear layers (fuse_gated_mlps
+    followed by the usual cast) must leave the f32 absmax and the packed bytes exactly as they are - in the running layer,
+    in state_dict() and after a load_state_dict round trip - as TorchFP4Linear._apply already guarantees."""
+    from torch_bnb_fp4 import fused
+
+    monkeypatch.setattr(fused, "ext", fake)
+    monkeypatch.setattr(fused, "fp4_code", lambda: torch.from_numpy(o.TREE_TABLE.copy()))
+    M, K = 32, 128
+    rng = np.random.default_rng(8)
+    # scales that do not survive a 16-bit rounding: tiny (fp16 subnormal / flush range) and with a full f32 mantissa
+    w = (rng.standard_normal(M * K) * np.repeat(10.0 ** rng.uniform(-7, 0, M * K // 64), 64)).astype(np.float32)
+    p, a = o.quantize_fp4(w, 64)
+    assert (torch.from_numpy(a).half().float().numpy() != a).any() and (torch.from_numpy(a).bfloat16().float().numpy() != a).any()
+    bias = torch.randn(M)
+
+    def fresh():
+        return fused.FusedFP4Linear.from_packed(torch.from_numpy(p.copy()).view(-1, 1), torch.from_numpy(a.copy()), (M, K), 64, bias.clone())
+
+    for cast in (lambda m: m.half(), lambda m: m.to(torch.bfloat16), lambda m: m.to("cpu", torch.float16), lambda m: m.float()):
+        holder = nn.Sequential(fresh())
+        layer = cast(holder)[0]
+        for scales in (layer.absmax, layer.quant_data.absmax, layer.state_dict()["absmax"]):
+            assert scales.dtype == torch.float32 and np.array_equal(scales.numpy(), a)
+        assert layer.qweight.dtype == torch.uint8 and np.array_equal(layer.qweight.numpy().reshape(-1), p)
+        assert layer.quant_data.A.data_ptr() == layer.qweight.data_ptr() and layer.quant_data.absmax.data_ptr() == layer.absmax.data_ptr()
+        # state_dict round trip into a fresh layer (different scales to start from): bit-identical scales again
+        other = fused.FusedFP4Linear.from_packed(torch.zeros(M * K // 2, 1, dtype=torch.uint8), torch.ones(M * K // 64), (M, K), 64, bias.clone())
+        other.load_state_dict(layer.state_dict())
+        assert other.absmax.dtype == torch.float32 and np.array_equal(other.quant_data.absmax.numpy(), a)
+        assert np.array_equal(other.quant_data.A.numpy().reshape(-1), p)
+        # and the layer still computes with the exact scales
+        x = torch.randn(1, K).to(torch.bfloat16)
+        y = layer(x)
+        want = o.linear_epilogue(o.gemv_exact(x.float().numpy().reshape(-1), p, a, M, K, 64), "bfloat16", bias.to(torch.bfloat16).float().numpy())
+        assert np.array_equal(y.float().numpy().reshape(-1), want)

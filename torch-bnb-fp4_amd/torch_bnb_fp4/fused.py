@@ -100,10 +100,17 @@ class FusedFP4Linear(nn.Module):
         return cls.gate_up_from_packed((g.A, g.absmax), (u.A, u.absmax), (g.M, g.N), g.blocksize, g.bias, u.bias)
 
     def _apply(self, fn, recurse=True):
-        super()._apply(fn, recurse)
-        qd = self.quant_data
-        if self.qweight.device != qd.A.device:  # device move: the dispatcher follows the buffers
-            qd.rebind(self.qweight, self.absmax, qd.code.to(self.qweight.device), self.bias)
+        # Only device moves are honoured, exactly as in TorchFP4Linear._apply: the packed bytes and the f32 scales never
+        # change dtype.  (nn.Module._apply would run model.half() / .to(torch.bfloat16) over the registered buffers and
+        # round absmax to 16 bits - silently degraded scales in the running layer and in state_dict().)
+        probe = fn(torch.empty(0, dtype=torch.float16, device=self.qweight.device))
+        if probe.device != self.qweight.device:
+            mv = lambda t: None if t is None else t.to(probe.device)
+            for name in ("qweight", "absmax", "bias"):
+                self._buffers[name] = mv(self._buffers[name])
+            qd = self.quant_data
+            qd.rebind(self.qweight, self.absmax, qd.code.to(probe.device), self.bias)
+            self._buffers["absmax"] = qd.absmax
             if qd.bias is not None:
                 self._buffers["bias"] = qd.bias
         return self
