@@ -1,0 +1,46 @@
+#!/bin/bash
+# Round-3 bounded experiment: does a load-time re-layout of the packed nibbles (and the full-rate v_bitop3_b32 sign merge) speed the
+# batch-1 GEMV up at the long / tall decode shapes?  Three builds of csrc/gemv_fp4.hip (baseline, -DFP4_EXP_BITOP3, -DFP4_EXP_RELAID)
+# linked with tools/exp_gemv.hip (cross-compiled beforehand into build_tmp/exp/, see profiles/r03_gemv_relayout_attempt.txt), timed
+# HBM-cold and cache-hot through the C ABI, then SQ counters of each build at 4096 x 14336.   Usage: tools/exp_relayout.sh OUTDIR
+set -e
+out=${1:-gpurun_out/r3_relayout}
+mkdir -p "$out"
+cd "$(dirname "$0")/.."
+for shape in "4096 4096" "28672 4096" "4096 14336"; do
+    for b in base bitop3 relaid; do
+        echo "### $b  $shape" | tee -a "$out/timing.txt"
+        ./build_tmp/exp/exp_gemv_$b $shape quick 2>&1 | grep -E "^M=|floor L2|gemv default" | tee -a "$out/timing.txt"
+    done
+done
+# a second pass in the opposite build order (clock / thermal drift shows up as a difference between the two passes)
+for shape in "4096 14336" "28672 4096" "4096 4096"; do
+    for b in relaid bitop3 base; do
+        echo "### $b  $shape (second pass)" | tee -a "$out/timing.txt"
+        ./build_tmp/exp/exp_gemv_$b $shape quick 2>&1 | grep -E "gemv default" | tee -a "$out/timing.txt"
+    done
+done
+export TMPDIR=/tmp
+for b in base bitop3 relaid; do
+    rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU \
+        -d "$out/pmc_$b" -o pmc --output-format csv -- ./build_tmp/exp/exp_gemv_$b 4096 14336 quick > "$out/pmc_$b.log" 2>&1 || echo "pmc $b failed" | tee -a "$out/timing.txt"
+done
+python3 - "$out" <<'PY'
+import csv, glob, sys, collections
+out = sys.argv[1]
+for b in ("base", "bitop3", "relaid"):
+    files = glob.glob(f"{out}/pmc_{b}/**/*counter_collection.csv", recursive=True)
+    if not files:
+        print(b, "no counter file"); continue
+    agg = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
+    for row in csv.DictReader(open(files[0])):
+        k = row["Kernel_Name"]
+        if "gemv16_regx" not in k: continue
+        agg[k][row["Counter_Name"]] += float(row["Counter_Value"])
+        if row["Counter_Name"] == "SQ_WAVES": n[k] += 1
+    for k, c in agg.items():
+        d = max(1, n[k])
+        line = f"{b:7s} {k[:60]:60s} launches {d:4d} " + " ".join(f"{name}={v / d:.0f}" for name, v in sorted(c.items()))
+        print(line)
+        open(f"{out}/sq_counters.txt", "a").write(line + "\n")
+PY

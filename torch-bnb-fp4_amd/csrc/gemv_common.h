@@ -18,8 +18,25 @@ __device__ __forceinline__ uint32_t perm(uint32_t hi, uint32_t lo, uint32_t sel)
 
 // One packed dword = 8 weights e0..e7 (byte b holds e_2b in its high nibble, e_2b+1 in its low
 // nibble).  Produces four 16-bit pairs of 12*code: P0=(e0,e2) P1=(e4,e6) P2=(e1,e3) P3=(e5,e7).
+// (FP4_EXP_* are experiment switches for tools/exp_gemv.hip only - never defined in the library build.  FP4_EXP_BITOP3: the two
+// sign merges as full-rate v_bitop3_b32 with the mask in a VGPR instead of half-rate v_and_or_b32; FP4_EXP_RELAID: that, plus a
+// load-time nibble permutation of every packed dword - byte 0 = (e0,e2), byte 1 = (e1,e3), byte 2 = (e4,e6), byte 3 = (e5,e7) - so
+// that the decoded pairs are (e0,e1) (e4,e5) (e2,e3) (e6,e7) and x is used as loaded, without its 16 v_perm per group.)
 template <int DT>
 __device__ __forceinline__ void decode8(uint32_t q, uint32_t (&P)[4]) {
+#if defined(FP4_EXP_BITOP3) || defined(FP4_EXP_RELAID)
+    if constexpr (DT == FP4_DTYPE_BF16) {
+        uint32_t m80;
+        asm("v_mov_b32 %0, 0x80808080" : "=v"(m80));
+        const uint32_t mhi = __builtin_amdgcn_bitop3_b32(q, m80, perm(kE4M3Hi, kE4M3Lo, (q >> 4) & 0x07070707u), 0xEA);
+        const uint32_t mlo = __builtin_amdgcn_bitop3_b32(q << 4, m80, perm(kE4M3Hi, kE4M3Lo, q & 0x07070707u), 0xEA);
+        P[0] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(mhi, 1.0f, false));
+        P[1] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(mhi, 1.0f, true));
+        P[2] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(mlo, 1.0f, false));
+        P[3] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(mlo, 1.0f, true));
+        return;
+    }
+#endif
     const uint32_t lo_sel = q & 0x07070707u;         // magnitudes of e1,e3,e5,e7
     const uint32_t hi_sel = (q >> 4) & 0x07070707u;  // magnitudes of e0,e2,e4,e6
     const uint32_t lo_sgn = (q & 0x08080808u) << 4;  // sign -> bit 7 of each byte

@@ -269,10 +269,14 @@ __global__ __launch_bounds__(WAVES * 64, (G >= 4 ? 4 : 1)) void gemv16_regx_kern
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const u32x4 w = xraw[g][q];
+#ifdef FP4_EXP_RELAID
+            xd[g][q] = u32x4{w.x, w.z, w.y, w.w};  // pairs (x0,x1) (x4,x5) (x2,x3) (x6,x7): register renaming only
+#else
             xd[g][q].x = perm(w.y, w.x, 0x05040100u);
             xd[g][q].y = perm(w.w, w.z, 0x05040100u);
             xd[g][q].z = perm(w.y, w.x, 0x07060302u);
             xd[g][q].w = perm(w.w, w.z, 0x07060302u);
+#endif
         }
     };
     if constexpr (!GMAJOR) {
