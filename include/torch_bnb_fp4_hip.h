@@ -85,8 +85,12 @@ FP4_HIP_API int fp4_hip_dequantize_blockwise(const uint8_t *packed, const float 
  * K must be even; K % 32 == 0 with a power-of-two blocksize >= 32 dividing K takes
  * the fast path (the reference's own GEMV gate, torch_bnb_fp4/__init__.py:593).
  * Replaces gemv_4bit_inference (csrc/gemv_fp4_optimized.cu:277-368; kernels :60-157
- * half/bf16 and :159-259 float).  Always uses the CODE_PARAM table, as the
- * reference does (its `datatype` tensor is ignored, csrc/gemv_fp4_optimized.cu:266,274).
+ * half/bf16 and :159-259 float).  The code values are those of the reference's GEMV, which ignores
+ * its `datatype` tensor and uses CODE_PARAM (csrc/gemv_fp4_optimized.cu:266,274): the f32 kernels
+ * read the bit-faithful CODE_PARAM f32 table; the f16 / bf16 kernels decode the exact k/12 values
+ * (12 * |code| is exact in 16 bits, and CODE_PARAM rounded to f16 / bf16 - what the reference's
+ * 16-bit kernels load, :92-96 - equals k/12 rounded to that type, tests/test_oracle.py), so the
+ * two are indistinguishable there.
  */
 FP4_HIP_API int fp4_hip_gemv(const void *x, const uint8_t *packed, const float *absmax, const void *bias, void *out, int64_t M,
                  int64_t K, int blocksize, int dtype, void *stream);

@@ -33,6 +33,31 @@ def test_exhaustive_bytes_and_absmax_index(golden):
         assert (bits(out) == np_bits(want)).all()
 
 
+def test_config_c1_fixture_through_the_hip_path(golden):
+    """BASELINE config 1 (1024x1024 Linear, blocksize 64, dequant to f32) is CPU-only by definition, but its committed fixture is
+    the one golden vector that digests a FULL problem: the seed-0 weight regenerates bit for bit (slice pinned in the fixture), the
+    HIP quantiser must reproduce the fixture's packed / absmax digests and fp4_hip_dequantize_blockwise of those bytes the digest
+    of the f32 output (tests/golden/make_golden.py:67-74) - through the C ABI and through the reference's op surface."""
+    import torch_bnb_fp4 as pkg
+
+    sha = lambda a: np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), np.uint8)
+    w = np.random.default_rng(0).standard_normal(1024 * 1024).astype(np.float32)
+    assert (w[123456:123456 + 1024] == golden["c1_w_slice"]).all()
+    P, A = hipabi.quantize(to_dev(w), 64)
+    assert (sha(P.cpu().numpy()) == golden["c1_packed_sha256"]).all() and (sha(A.cpu().numpy()) == golden["c1_absmax_sha256"]).all()
+    out = hipabi.dequantize(P, A, 64, w.size, torch.float32)
+    assert (sha(out.cpu().numpy()) == golden["c1_out_sha256"]).all()
+    assert (out[123456:123456 + 1024].cpu().numpy() == golden["c1_out_slice"]).all()
+    # every geometry of the tile kernel gives the same digest, and so does the op the reference's wrapper calls
+    for variant in (1, 2, 4, 8, 16, 2 | 256):
+        hipabi.set_variant("dequant", variant)
+        assert (sha(hipabi.dequantize(P, A, 64, w.size, torch.float32).cpu().numpy()) == golden["c1_out_sha256"]).all(), variant
+    hipabi.set_variant("dequant", -1)
+    code = pkg.ext.code_table("codebook").to(dev())
+    via_op = pkg.dequantize_fp4_codebook_invoke(P.view(-1, 1), A, code, 64, 1024, 1024, w.size, torch.float32)
+    assert via_op.shape == (1024, 1024) and (sha(via_op.cpu().numpy()) == golden["c1_out_sha256"]).all()
+
+
 @pytest.mark.parametrize("name,tb", TABLES)
 @pytest.mark.parametrize("dtype,key", [(torch.float32, "f32"), (torch.float16, "f16"), (torch.bfloat16, "bf16")])
 def test_rounding_kat_ties_subnormals_sweep(golden, name, tb, dtype, key):
@@ -56,17 +81,37 @@ def test_ragged_tails(golden, tag):
     assert (np.frombuffer(h.digest(), np.uint8) == golden[f"kat4{tag}_sha256"]).all()
 
 
+_FULL = {}
+
+
+def _full_size_case(dtype):
+    """Random bytes + scales of one 4096 x 4096 weight on the device and the C oracle's output bits per dtype (computed once)."""
+    n = 4096 * 4096
+    if "in" not in _FULL:
+        rng = np.random.default_rng(100)
+        packed = rng.integers(0, 256, n // 2, dtype=np.uint8)
+        am = (rng.random(n // 64, dtype=np.float32) * 0.1 + 0.01).astype(np.float32)
+        _FULL["in"] = (packed, am, to_dev(packed), to_dev(am))
+    packed, am, P, A = _FULL["in"]
+    if dtype not in _FULL:
+        _FULL[dtype] = np_bits(c_oracle.dequantize(packed, am, 64, n, NPDT[dtype]))
+    return P, A, _FULL[dtype]
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("variant", [-1, 1, 2, 4, 8, 16, 8 | 256, 2 | 256])
 def test_full_size_4096x4096_bit_exact_every_variant(dtype, variant):
     M = K = 4096
     n = M * K
-    rng = np.random.default_rng(100)
-    packed = rng.integers(0, 256, n // 2, dtype=np.uint8)
-    am = (rng.random(n // 64, dtype=np.float32) * 0.1 + 0.01).astype(np.float32)
-    want = np_bits(c_oracle.dequantize(packed, am, 64, n, NPDT[dtype]))
+    P, A, want = _full_size_case(dtype)
     hipabi.set_variant("dequant", variant)
-    out = hipabi.dequantize(to_dev(packed), to_dev(am), 64, n, dtype)
+    if dtype != torch.float32 and variant in (16, 8 | 256):
+        # not built for 16-bit output (sweep-only geometries removed in round 3): refused, never computed
+        out = torch.empty(n, dtype=dtype, device=dev())
+        rc = hipabi.lib().fp4_hip_dequantize_blockwise(P.data_ptr(), A.data_ptr(), out.data_ptr(), 64, n, hipabi.DT[dtype], 0, 0, None)
+        assert rc == hipabi.ERR_INVALID and "unknown kernel variant" in hipabi.last_error()
+        return
+    out = hipabi.dequantize(P, A, 64, n, dtype)
     torch.cuda.synchronize()
     assert np.array_equal(bits(out), want)
 

@@ -16,7 +16,7 @@ import pytest
 import torch
 
 import hipabi
-from gpu_util import NPDT, bits, dev, to_dev, torch_values
+from gpu_util import NPDT, bits, case, dev, to_dev, torch_values
 from oracle import c_oracle, fp4_oracle as o
 
 pytestmark = pytest.mark.gpu
@@ -26,12 +26,16 @@ SHAPES = [(4096, 4096), (28672, 4096), (4096, 14336), (6144, 4096), (64, 768), (
           (36, 28672), (132, 5120), (70, 6144), (4100, 8192), (34, 16384), (2, 64)]
 
 
-def make_case(M, K, seed, bs=64):  # noqa: D103
-    rng = np.random.default_rng(seed)
-    w = (rng.standard_normal(M * K) * 0.02).astype(np.float32)
-    packed, am = c_oracle.quantize(w, bs)
-    return packed, am, rng.standard_normal(K).astype(np.float32), rng.standard_normal(M).astype(np.float32) * 0.1, \
-        rng.standard_normal(M).astype(np.float32)
+def make_case(M, K, seed=None, bs=64):
+    """(packed, absmax, x, bias, res) of the session-cached case of this shape (gpu_util.case: quantised once by the CPU oracle and
+    shared by every test function and parameter that works on the shape)."""
+    c = case(M, K, bs, 1000003 * M + K if seed is None else seed)
+    return c.packed, c.am, c.x, c.bias, c.res
+
+
+def dev_case(M, K, bs=64):
+    c = case(M, K, bs, 1000003 * M + K)
+    return c.P, c.A
 
 
 def as_np(t):
@@ -42,8 +46,8 @@ def as_np(t):
 @pytest.mark.parametrize("M,K", SHAPES + [(5, 64), (33, 24), (257, 2112)])
 def test_bias_residual_epilogue_is_bit_exact(dtype, M, K):
     bs = 64 if K % 64 == 0 else 8
-    packed, am, x, bias, res = make_case(M, K, M * 3 + K, bs)
-    P, A = to_dev(packed), to_dev(am)
+    packed, am, x, bias, res = make_case(M, K, bs=bs)
+    P, A = dev_case(M, K, bs)
     x_t, b_t, r_t = torch_values(x, dtype), torch_values(bias, dtype), torch_values(res, dtype)
     plain = hipabi.gemv(x_t, P, A, M, K, bs)
     for use_bias, use_res in ((False, True), (True, True), (True, False), (False, False)):
@@ -72,8 +76,8 @@ def ulp_distance(a_bits, b_bits):
 @pytest.mark.parametrize("with_bias", [False, True])
 @pytest.mark.parametrize("M,K", [s for s in SHAPES if s[0] % 2 == 0])
 def test_gate_up_epilogue(dtype, M, K, with_bias):
-    packed, am, x, bias, res = make_case(M, K, M * 5 + K)
-    P, A = to_dev(packed), to_dev(am)
+    packed, am, x, bias, res = make_case(M, K)
+    P, A = dev_case(M, K)
     x_t = torch_values(x * 2.0, dtype)  # gate values spread over a few units: silu is exercised off its linear part
     b_t = torch_values(bias, dtype) if with_bias else None
     r_t = torch_values(res[: M // 2], dtype)
@@ -98,10 +102,11 @@ def test_gate_up_against_float64_oracle_end_to_end():
     """The whole fused launch against float64: silu(g*) * u* with g*, u* the exact sums; the tolerance is the rounding chain
     of the unfused model code (three roundings to bf16 + the GEMV's own bar)."""
     M, K = 28672, 4096
-    packed, am, x, _, _ = make_case(M, K, 77)
+    c = case(M, K, 64, 1000003 * M + K)
+    packed, am, x = c.packed, c.am, c.x
     x_t = torch_values(x, torch.bfloat16)
-    got = as_np(hipabi.gemv_fused(x_t, to_dev(packed), to_dev(am), M, K, 64, None, None, hipabi.EPILOGUE_SILU_MUL_PAIRS)).astype(np.float64)
-    exact = c_oracle.gemv_f64(as_np(x_t).astype(np.float64), packed, am, M, K, 64)
+    got = as_np(hipabi.gemv_fused(x_t, c.P, c.A, M, K, 64, None, None, hipabi.EPILOGUE_SILU_MUL_PAIRS)).astype(np.float64)
+    exact, _ = c.exact(x_t, tag=("x", torch.bfloat16))
     g, u = exact[0::2], exact[1::2]
     sil = g / (1.0 + np.exp(-g))
     want = sil * u
@@ -216,9 +221,9 @@ def test_small_batch_epilogues(dtype, B, M, K):
     small-batch product (same kernel, same sum); the gated epilogue within 1 ulp of torch's silu(g) * u on that product's
     gate / up columns, >= 99.8 % identical; every kernel family (persistent / one-shot matrix-core, VALU fallback) and the
     17..32-row split over two launches."""
-    packed, am, x, bias, res = make_case(M, K, M * 7 + K + B)
+    packed, am, x, bias, res = make_case(M, K)
     rng = np.random.default_rng(B)
-    P, A = to_dev(packed), to_dev(am)
+    P, A = dev_case(M, K)
     xb = torch_values(rng.standard_normal((B, K)).astype(np.float32), dtype)
     b_t = torch_values(bias, dtype)
     r_t = torch_values(rng.standard_normal((B, M)).astype(np.float32), dtype)

@@ -15,14 +15,14 @@ import pytest
 import torch
 
 import hipabi
-from gpu_util import NPDT, dev, to_dev, torch_values
+from gpu_util import HALF_ULP, NPDT, assert_within_bar, case, dev, to_dev, torch_values
 from oracle import c_oracle, fp4_oracle as o
 
 pytestmark = pytest.mark.gpu
 DTYPES = [torch.bfloat16, torch.float16, torch.float32]
-HALF_ULP = {torch.bfloat16: 2.0**-8, torch.float16: 2.0**-11, torch.float32: 0.0}
-VARIANTS16 = [r | (w << 8) | (u << 16) for (r, w, u) in
-              [(1, 4, 1), (1, 4, 2), (2, 4, 2), (1, 8, 2), (2, 8, 2), (1, 16, 2)]] + [(1 << 24) | it for it in (1, 2, 4, 8)]  # + register-x family
+# every 16-bit geometry the library builds for this shape: the LDS geometry (north-star mapping at 4 and 8 waves) + the register-x
+# family at 1 / 2 / 4 row pairs per group (round 3 removed the sweep-only instantiations, profiles/r03_kernel_inventory.txt)
+VARIANTS16 = [r | (w << 8) | (u << 16) for (r, w, u) in [(1, 4, 2), (1, 8, 2)]] + [(1 << 24) | it for it in (1, 2, 4)]
 
 
 @pytest.fixture(autouse=True)
@@ -33,27 +33,34 @@ def _default_variant():
 
 
 def make_case(M, K, bs=64, seed=0, wscale=0.02):
-    rng = np.random.default_rng(seed)
-    w = (rng.standard_normal(M * K) * wscale).astype(np.float32)
-    packed, am = c_oracle.quantize(w, bs) if bs >= 2 else o.quantize_fp4(w, bs)
-    x = rng.standard_normal(K).astype(np.float32)
-    return packed, am, x
+    """(packed, absmax, x) of the session-cached case (gpu_util.case): the oracle quantises each (shape, seed) once."""
+    c = case(M, K, bs, seed, wscale)
+    return c.packed, c.am, c.x
+
+
+def shape_seed(M, K):
+    """One seed per shape, so that every test function working on a shape shares its quantised weight and float64 answers."""
+    return 1000003 * M + K
+
+
+def check_case(y: torch.Tensor, c, dtype, x_t=None):
+    """Bar 1 for the case's own activation vector (its float64 answer is computed once per dtype and shared)."""
+    if x_t is None:
+        x_t = torch_values(c.x, dtype)
+    exact, scale = c.exact(x_t, tag=("x", dtype))
+    return exact, assert_within_bar(y, exact, scale, dtype)
 
 
 def check(y: torch.Tensor, x_t: torch.Tensor, packed, am, M, K, bs, dtype, bias=None):
+    """Bar 1 for explicit operands (no caching: golden vectors and one-off inputs)."""
     xv = x_t.float().cpu().numpy().astype(np.float64)
     exact = c_oracle.gemv_f64(xv, packed, am, M, K, bs) if K % 2 == 0 else o.gemv_exact(xv, packed, am, M, K, bs)
     wabs = np.abs(o.dequantize_f32(packed, am, bs, M * K).reshape(M, K).astype(np.float64))
     scale = wabs @ np.abs(xv)
-    got = y.float().cpu().numpy().astype(np.float64)
     if bias is not None:
         # bias semantics are exact (T(T(sum) + bias)), checked separately; compare pre-bias here
         raise AssertionError("use check() without bias")
-    tol = HALF_ULP[dtype] * 1.01 * np.abs(exact) + 1e-5 * scale + 1e-30
-    err = np.abs(got - exact)
-    worst = int(np.argmax(err - tol))
-    assert (err <= tol).all(), (worst, got[worst], exact[worst], err[worst], tol[worst])
-    return exact, err
+    return exact, assert_within_bar(y, exact, scale, dtype)
 
 
 @pytest.mark.parametrize("tag", list("abc"))
@@ -78,10 +85,11 @@ def test_bar2_reference_emulation_at_decode_shapes(dtype, M, K):
     absmax, T multiply, T accumulate per lane, f32 tree reduce: csrc/gemv_fp4_optimized.cu:87-156).  The kernel runs on
     the full matrix; the (row-independent) emulation is evaluated on the first 512 rows to bound the test's run time."""
     rows = 512
-    packed, am, x = make_case(M, K, seed=5 + K)
-    x_t = torch_values(x, dtype)
-    y = hipabi.gemv(x_t, to_dev(packed), to_dev(am), M, K, 64)
-    exact, err = check(y, x_t, packed, am, M, K, 64, dtype)  # bar 1 on every row
+    c = case(M, K, seed=shape_seed(M, K))
+    packed, am = c.packed, c.am
+    x_t = torch_values(c.x, dtype)
+    y = hipabi.gemv(x_t, c.P, c.A, M, K, 64)
+    exact, err = check_case(y, c, dtype, x_t)  # bar 1 on every row
     xv = x_t.float().cpu().numpy()
     p_s, a_s = packed[: rows * K // 2], am[: rows * K // 64]
     emu = o.gemv_reference_emulated(xv, p_s, a_s, rows, K, 64, NPDT[dtype]).astype(np.float64)
@@ -95,52 +103,57 @@ def test_bar2_reference_emulation_at_decode_shapes(dtype, M, K):
 @pytest.mark.parametrize("variant", VARIANTS16)
 def test_4096x4096_every_variant(dtype, variant):
     M = K = 4096
-    packed, am, x = make_case(M, K, seed=1)
-    x_t = torch_values(x, dtype)
+    c = case(M, K, seed=shape_seed(M, K))
+    x_t = torch_values(c.x, dtype)
     hipabi.set_variant("gemv", variant)
-    y = hipabi.gemv(x_t, to_dev(packed), to_dev(am), M, K, 64)
-    check(y, x_t, packed, am, M, K, 64, dtype)
+    y = hipabi.gemv(x_t, c.P, c.A, M, K, 64)
+    check_case(y, c, dtype, x_t)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("M,K", [(14336, 4096), (4096, 14336), (1024, 4096), (2048, 768), (64, 2048), (66, 768), (5, 64), (1, 32),
                                  (3, 8192), (257, 2112), (130, 11008), (70, 13824), (130, 7168), (37, 28672), (5120, 5120), (70, 10240), (133, 6144), (4099, 8192)])
 def test_model_shapes(dtype, M, K):
-    packed, am, x = make_case(M, K, seed=M + K)
-    x_t = torch_values(x, dtype)
-    y = hipabi.gemv(x_t, to_dev(packed), to_dev(am), M, K, 64)
-    check(y, x_t, packed, am, M, K, 64, dtype)
+    c = case(M, K, seed=shape_seed(M, K))
+    x_t = torch_values(c.x, dtype)
+    y = hipabi.gemv(x_t, c.P, c.A, M, K, 64)
+    check_case(y, c, dtype, x_t)
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("iters", [1, 2, 4, 8])
+@pytest.mark.parametrize("iters", [1, 2, 4])
 @pytest.mark.parametrize("M,K", [(14336, 4096), (4096, 14336), (1024, 4096), (2048, 768), (64, 2048), (66, 768), (5, 64), (1, 32),
                                  (3, 8192), (257, 2112), (100, 16384), (7, 32768), (33, 1024), (19, 2048), (130, 11008), (9, 12288)])
 def test_register_x_geometry_all_band_splits(dtype, iters, M, K):  # noqa: D401
     """The second GEMV geometry (x in registers, K split across waves): every KSPLIT x G instantiation,
     ragged M, idle lanes, and the K > 16384 fall-back to the LDS geometry."""
-    packed, am, x = make_case(M, K, seed=M * 7 + K)
-    x_t = torch_values(x, dtype)
+    c = case(M, K, seed=shape_seed(M, K))
+    x_t = torch_values(c.x, dtype)
     hipabi.set_variant("gemv", (1 << 24) | iters)
-    y = hipabi.gemv(x_t, to_dev(packed), to_dev(am), M, K, 64)
-    check(y, x_t, packed, am, M, K, 64, dtype)
+    y = hipabi.gemv(x_t, c.P, c.A, M, K, 64)
+    check_case(y, c, dtype, x_t)
+
+
+# (M, K, bands, row pairs per group): five / six bands at 1 / 2 / 4 row pairs; seven and eight bands at the one depth-specific setting
+# that is built (7168 -> 2, 14336 -> 4, 28672 -> 2; 8192 -> 2 or 4); the last three land on the standard split (their band
+# geometries are not built: 12288 six-band, 16384 / 32768 eight-band) and must still be right.
+BAND_CASES = ([(M, K, b, it) for (M, K, b) in [(66, 5120, 5), (131, 10240, 5), (2048, 5120, 5), (66, 6144, 6)] for it in (1, 2, 4)] +
+              [(66, 7168, 7, 2), (5, 7168, 7, 2), (4096, 14336, 7, 4), (130, 14336, 7, 4), (37, 28672, 7, 2),
+               (4100, 8192, 8, 2), (4100, 8192, 8, 4), (66, 8192, 8, 2), (35, 12288, 6, 2), (40, 16384, 8, 2), (9, 32768, 8, 2)])
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("iters", [1, 2, 4])
-@pytest.mark.parametrize("M,K,bands", [(4096, 14336, 7), (66, 7168, 7), (130, 14336, 7), (37, 28672, 7), (5, 7168, 7), (66, 5120, 5),
-                                       (131, 10240, 5), (2048, 5120, 5), (66, 6144, 6), (35, 12288, 6), (4100, 8192, 8), (66, 8192, 8),
-                                       (40, 16384, 8), (9, 32768, 8)])
-def test_register_x_five_six_seven_band_geometries(dtype, iters, M, K, bands):
-    """K = 5 / 6 / 7 / 8 band widths x {1, 2, 4}: as many waves as bands, 1 / 2 / 4 groups per lane, ragged M."""
-    packed, am, x = make_case(M, K, seed=M * 11 + K)
-    x_t = torch_values(x, dtype)
+@pytest.mark.parametrize("M,K,bands,iters", BAND_CASES)
+def test_register_x_five_six_seven_band_geometries(dtype, M, K, bands, iters):
+    """K = 5 / 6 / 7 / 8 band widths: as many waves as bands, 1 / 2 / 4 groups per lane, ragged M."""
+    c = case(M, K, seed=shape_seed(M, K))
+    x_t = torch_values(c.x, dtype)
     try:
         hipabi.set_variant("gemv", (1 << 24) | (bands << 8) | iters)
-        y = hipabi.gemv(x_t, to_dev(packed), to_dev(am), M, K, 64)
+        y = hipabi.gemv(x_t, c.P, c.A, M, K, 64)
     finally:
         hipabi.set_variant("gemv", -1)
-    check(y, x_t, packed, am, M, K, 64, dtype)
+    check_case(y, c, dtype, x_t)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -233,7 +246,7 @@ def test_partial_f32_output_and_k_split_sum(dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("kernel", [-1, 0, 1 | (1 << 4), 1 | (2 << 4), 1 | (1 << 4) | (1 << 8), 1 | (2 << 4) | (1 << 8), 1 | (1 << 4) | (2 << 14)])  # VALU kernel; matrix-core kernel: 1 / 2 row tiles, LDS-staged / direct weight loads, 8 blocks per pass wherever they divide K
+@pytest.mark.parametrize("kernel", [-1, 0, 1 | (1 << 4), 1 | (2 << 4), 1 | (1 << 4) | (2 << 14)])  # default; VALU kernel; matrix-core kernel: 1 / 2 row tiles, 8 blocks per pass wherever they divide K
 @pytest.mark.parametrize("B", [1, 2, 4, 5, 8, 9, 13, 16])
 @pytest.mark.parametrize("M,K", [(4096, 4096), (1024, 4096), (2048, 768), (66, 2048), (257, 1024), (300, 8192), (40, 14336), (33, 512),
                                  (130, 11008), (48, 1472), (70, 5120), (36, 13824)])
@@ -243,28 +256,18 @@ def test_small_batch_fused_gemm(dtype, kernel, B, M, K):
     beyond the VALU kernel's reach (11008 = Llama-2-7B's down projection, 1472 = 23 blocks) lands on the one-pass kernels of
     gemm_wide_fp4.hip with one column tile and a ragged last step; so do, in the default dispatch, K = 5120 from 5 rows and K = 13824
     (one or two quant blocks per wave and pass on the 16-row matrix-core kernel)."""
-    packed, am, _ = make_case(M, K, seed=B * 1000 + M)
-    rng = np.random.default_rng(B)
-    x = rng.standard_normal((B, K)).astype(np.float32)
-    bias = rng.standard_normal(M).astype(np.float32) * 0.1
-    x_t, b_t = torch_values(x, dtype), torch_values(bias, dtype)
+    c = case(M, K, seed=shape_seed(M, K))
+    x_t, b_t, exact, scale = c.rows(B, B, dtype)
     kernel_is_mfma = kernel & 1
     valu_ok = B <= 8 and ((K // 32 <= 128) or (K // 32 <= 256 and B <= 4) or (K // 32 <= 512 and B <= 2))
     mfma_ok = K % 512 == 0
     hipabi.set_variant("gemm_small", kernel)
     try:
         assert valu_ok or mfma_ok or K % 64 == 0
-        y = hipabi.gemm_small(x_t, to_dev(packed), to_dev(am), M, K, 64, bias=b_t)
+        y = hipabi.gemm_small(x_t, c.P, c.A, M, K, 64, bias=b_t)
     finally:
         hipabi.set_variant("gemm_small", -1)
-    wabs = np.abs(o.dequantize_f32(packed, am, 64, M * K).reshape(M, K).astype(np.float64))
-    bv = b_t.float().cpu().numpy().astype(np.float64)
-    for b in range(B):
-        xv = x_t[b].float().cpu().numpy().astype(np.float64)
-        exact = c_oracle.gemv_f64(xv, packed, am, M, K, 64) + bv
-        scale = wabs @ np.abs(xv) + np.abs(bv)
-        err = np.abs(y[b].float().cpu().numpy() - exact)
-        assert (err <= HALF_ULP[dtype] * 1.01 * np.abs(exact) + 1e-5 * scale + 1e-30).all(), (b, err.max())
+    assert_within_bar(y, exact, scale, dtype)
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
@@ -277,12 +280,9 @@ def test_small_batch_persistent_kernel(dtype, B, M):
     1250 tiles over 512 / 256 workgroups, i.e. the prefetch-next-tile loop).  Same bar as every other small-batch kernel, and
     bit-identical to the one-shot kernel (same tile arithmetic, same summation order)."""
     K = 4096
-    packed, am, _ = make_case(M, K, seed=B * 77 + M)
-    rng = np.random.default_rng(B + M)
-    x = rng.standard_normal((B, K)).astype(np.float32)
-    bias = rng.standard_normal(M).astype(np.float32) * 0.1
-    x_t, b_t = torch_values(x, dtype), torch_values(bias, dtype)
-    P, A = to_dev(packed), to_dev(am)
+    c = case(M, K, seed=shape_seed(M, K))
+    x_t, b_t, exact, scale = c.rows(B, B + M, dtype)
+    P, A = c.P, c.A
     try:
         hipabi.set_variant("gemm_small", 1 | (2 << 10))
         y = hipabi.gemm_small(x_t, P, A, M, K, 64, bias=b_t)
@@ -291,14 +291,7 @@ def test_small_batch_persistent_kernel(dtype, B, M):
     finally:
         hipabi.set_variant("gemm_small", -1)
     assert torch.equal(y, y_one_shot)
-    wabs = np.abs(o.dequantize_f32(packed, am, 64, M * K).reshape(M, K).astype(np.float64))
-    bv = b_t.float().cpu().numpy().astype(np.float64)
-    for b in range(B):
-        xv = x_t[b].float().cpu().numpy().astype(np.float64)
-        exact = c_oracle.gemv_f64(xv, packed, am, M, K, 64) + bv
-        scale = wabs @ np.abs(xv) + np.abs(bv)
-        err = np.abs(y[b].float().cpu().numpy() - exact)
-        assert (err <= HALF_ULP[dtype] * 1.01 * np.abs(exact) + 1e-5 * scale + 1e-30).all(), (b, err.max())
+    assert_within_bar(y, exact, scale, dtype)
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
@@ -307,11 +300,9 @@ def test_small_batch_persistent_kernel(dtype, B, M):
 def test_small_batch_beyond_16_rows_chunked_path(dtype, B, M, K):
     """17..64 rows with the one-pass kernel switched off: evenly split over ceil(B/16) launches; each row of the result equals
     what a single-chunk call on that row's chunk gives (bit for bit) and meets the GEMV bar against the float64 product."""
-    packed, am, _ = make_case(M, K, seed=B + M)
-    rng = np.random.default_rng(B * 3 + K)
-    x = rng.standard_normal((B, K)).astype(np.float32)
-    x_t = torch_values(x, dtype)
-    P, A = to_dev(packed), to_dev(am)
+    c = case(M, K, seed=shape_seed(M, K))
+    x_t, _, exact, scale = c.rows(B, B * 3 + K, dtype, bias=False)
+    P, A = c.P, c.A
     hipabi.set_variant("gemm_wide", 0)
     try:
         y = hipabi.gemm_small(x_t, P, A, M, K, 64)
@@ -321,24 +312,16 @@ def test_small_batch_beyond_16_rows_chunked_path(dtype, B, M, K):
     per = -(-B // chunks)
     parts = [hipabi.gemm_small(x_t[b0:b0 + per].contiguous(), P, A, M, K, 64) for b0 in range(0, B, per)]
     assert torch.equal(y, torch.cat(parts))
-    wabs = np.abs(o.dequantize_f32(packed, am, 64, M * K).reshape(M, K).astype(np.float64))
-    for b in (0, 15, 16, B - 1):
-        xv = x_t[b].float().cpu().numpy().astype(np.float64)
-        exact = c_oracle.gemv_f64(xv, packed, am, M, K, 64)
-        err = np.abs(y[b].float().cpu().numpy() - exact)
-        assert (err <= HALF_ULP[dtype] * 1.01 * np.abs(exact) + 1e-5 * (wabs @ np.abs(xv)) + 1e-30).all(), (b, err.max())
+    assert_within_bar(y, exact, scale, dtype)
 
 
 WIDE_SHAPES = [(4096, 4096), (1024, 4096), (300, 8192), (66, 2048), (33, 512), (130, 14336), (257, 1024), (130, 11008), (66, 768), (40, 1472)]
-_WIDE_CASES = {}
 
 
 def wide_case(M, K):
-    """One weight per shape, with its exact f32 values as float64 (shared by the parametrised cases below)."""
-    if (M, K) not in _WIDE_CASES:
-        packed, am, _ = make_case(M, K, seed=31 + M)
-        _WIDE_CASES[(M, K)] = (packed, am, o.dequantize_f32(packed, am, 64, M * K).reshape(M, K).astype(np.float64))
-    return _WIDE_CASES[(M, K)]
+    """One weight per shape (session-cached), with its exact f32 values as float64."""
+    c = case(M, K, seed=shape_seed(M, K))
+    return c.packed, c.am, c.w64()
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
@@ -351,25 +334,14 @@ def test_wide_batch_one_pass_kernel(dtype, cfg, B, M, K):
     130, 257, 300: clamped rows, last workgroup partly empty), B not a multiple of 16 (clamped columns), 1..56 steps per K slice
     (fewer steps than the weight ring is deep, exactly as many, more).  Every row of the result meets
     the GEMV bar against the float64 product (bias added before the one rounding, as F.linear does)."""
-    packed, am, w = wide_case(M, K)
-    rng = np.random.default_rng(B * 7 + K + cfg)
-    x = rng.standard_normal((B, K)).astype(np.float32)
-    bias = rng.standard_normal(M).astype(np.float32) * 0.1
-    x_t, b_t = torch_values(x, dtype), torch_values(bias, dtype)
-    P, A = to_dev(packed), to_dev(am)
+    c = case(M, K, seed=shape_seed(M, K))
+    x_t, b_t, exact, scale = c.rows(B, B * 7 + K, dtype)  # (the float64 product is spot-checked against the C oracle's loop there)
     hipabi.set_variant("gemm_wide", cfg)
     try:
-        y = hipabi.gemm_small(x_t, P, A, M, K, 64, bias=b_t)
+        y = hipabi.gemm_small(x_t, c.P, c.A, M, K, 64, bias=b_t)
     finally:
         hipabi.set_variant("gemm_wide", -1)
-    xv = x_t.float().cpu().numpy().astype(np.float64)
-    bv = b_t.float().cpu().numpy().astype(np.float64)
-    exact = xv @ w.T + bv  # float64 product of the exact f32 weights: the oracle's gemv_f64, all rows at once
-    spot = c_oracle.gemv_f64(xv[B - 1], packed, am, M, K, 64) + bv
-    assert np.allclose(exact[B - 1], spot, rtol=1e-12, atol=1e-12)
-    scale = np.abs(xv) @ np.abs(w).T + np.abs(bv)
-    err = np.abs(y.float().cpu().numpy().astype(np.float64) - exact)
-    assert (err <= HALF_ULP[dtype] * 1.01 * np.abs(exact) + 1e-5 * scale + 1e-30).all(), float(err.max())
+    assert_within_bar(y, exact, scale, dtype)
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
@@ -380,23 +352,14 @@ def test_split_k_with_workspace(dtype, B, M, K):
     at 11008 and 8256, ragged rows, more tiles than waves and fewer): partial sums through the workspace + the reducing launch meet the GEMV bar
     against the float64 product; twice the same call gives the same bits (fixed summation order); without a workspace, or with one
     that is too small, the call is fp4_hip_gemm_small_fused and agrees with it bit for bit."""
-    packed, am, w = wide_case(M, K) if (M, K) in WIDE_SHAPES else (None, None, None)
-    if packed is None:
-        packed, am, _ = make_case(M, K, seed=77 + M)
-        w = o.dequantize_f32(packed, am, 64, M * K).reshape(M, K).astype(np.float64)
-    rng = np.random.default_rng(B * 13 + K)
-    x_t = torch_values(rng.standard_normal((B, K)).astype(np.float32), dtype)
-    b_t = torch_values(rng.standard_normal(M).astype(np.float32) * 0.1, dtype)
-    P, A = to_dev(packed), to_dev(am)
+    c = case(M, K, seed=shape_seed(M, K))
+    x_t, b_t, exact, scale = c.rows(B, B * 13 + K, dtype)
+    rng = np.random.default_rng(B * 17 + K)
+    P, A = c.P, c.A
     y, want_bytes = hipabi.gemm_small_ws(x_t, P, A, M, K, 64, bias=b_t)
     chunk = B if B <= 64 else (B + 1) // 2  # 65..128 rows: two even chunks through the same workspace
     assert want_bytes == (-(-(K // 64) // 8) * chunk * M * 4 if (chunk >= 33 and 16 <= M < 6144) else 0)  # (256 CUs: short = M < 6144)
-    xv = x_t.float().cpu().numpy().astype(np.float64)
-    bv = b_t.float().cpu().numpy().astype(np.float64)
-    exact = xv @ w.T + bv
-    scale = np.abs(xv) @ np.abs(w).T + np.abs(bv)
-    err = np.abs(y.float().cpu().numpy().astype(np.float64) - exact)
-    assert (err <= HALF_ULP[dtype] * 1.01 * np.abs(exact) + 1e-5 * scale + 1e-30).all(), float(err.max())
+    assert_within_bar(y, exact, scale, dtype)
     y2, _ = hipabi.gemm_small_ws(x_t, P, A, M, K, 64, bias=b_t)
     assert torch.equal(y, y2)
     small = torch.empty(max(16, want_bytes // 2), dtype=torch.uint8, device=dev())

@@ -184,13 +184,10 @@ int main(int argc, char **argv) {
 
     std::vector<std::pair<const char *, int>> variants = {
         {"lds r1 w4 u2", 1 | (4 << 8) | (2 << 16)},   {"lds r1 w8 u2", 1 | (8 << 8) | (2 << 16)},
-        {"lds r1 w16 u2", 1 | (16 << 8) | (2 << 16)}, {"lds r2 w4 u2", 2 | (4 << 8) | (2 << 16)},
         {"regx it1", (1 << 24) | 1},                  {"regx it2", (1 << 24) | 2},
-        {"regx it4", (1 << 24) | 4},                  {"regx it8", (1 << 24) | 8},
-        {"regx ks2 it1", (1 << 24) | (2 << 8) | 1}, {"regx ks2 it2", (1 << 24) | (2 << 8) | 2}, {"regx ks2 it4", (1 << 24) | (2 << 8) | 4},
-        {"regx ks1 it1", (1 << 24) | (1 << 8) | 1}, {"regx ks1 it2", (1 << 24) | (1 << 8) | 2},
-        {"regx 8waves it1", (1 << 24) | (8 << 8) | 1}, {"regx 8waves it2", (1 << 24) | (8 << 8) | 2},
-        {"regx 8waves it4", (1 << 24) | (8 << 8) | 4},
+        {"regx it4", (1 << 24) | 4},                  {"regx 5 bands it2", (1 << 24) | (5 << 8) | 2},
+        {"regx 6 bands it2", (1 << 24) | (6 << 8) | 2}, {"regx 7 bands", (1 << 24) | (7 << 8) | 2},
+        {"regx 8 bands it2", (1 << 24) | (8 << 8) | 2},  // (band geometries apply to the row lengths they were built for; elsewhere = the standard split)
         {"default heuristic", -1},
     };
     if (quick) variants = {{"default heuristic", -1}};

@@ -45,7 +45,7 @@ if what in ("dequant", "all"):
     for dt, name, isz in ((torch.bfloat16, "bf16", 2), (torch.float16, "f16", 2), (torch.float32, "f32", 4)):
         outs = [torch.empty(n, dtype=dt, device=dev) for _ in range(min(R, 32))]
         nbytes = n // 2 + 4 * (n // 64) + n * isz
-        for variant in (-1, 1, 2, 4, 8, 16, 1 | 256, 2 | 256, 4 | 256, 8 | 256, 16 | 256):
+        for variant in ((-1, 1, 2, 4, 8, 16, 1 | 256, 2 | 256, 4 | 256, 8 | 256, 16 | 256) if isz == 4 else (-1, 1, 2, 4, 8, 1 | 256, 2 | 256, 4 | 256)):  # what the library builds
             hipabi.set_variant("dequant", variant)
             cold = capture(lambda: [hipabi.dequantize(packed[i], absmax[i], 64, n, dt, out=outs[i % len(outs)]) for i in range(R)])
             hot = capture(lambda: [hipabi.dequantize(packed[0], absmax[0], 64, n, dt, out=outs[0]) for i in range(R)])
@@ -60,7 +60,7 @@ if what in ("gemv", "all"):
         x = torch.randn(K, device=dev).to(dt)
         ys = [torch.empty(M, dtype=dt, device=dev) for _ in range(R)]
         nbytes = n // 2 + 4 * (n // 64) + (K + M) * isz
-        for (r, w, u) in [(1, 4, 1), (1, 4, 2), (2, 4, 2), (1, 8, 2), (2, 8, 2), (1, 16, 2)]:
+        for (r, w, u) in [(1, 4, 2), (1, 8, 2)]:  # the LDS geometries the library builds
             hipabi.set_variant("gemv", r | (w << 8) | (u << 16))
             reps = 4
             cold = capture(lambda: [hipabi.gemv(x, packed[i % R], absmax[i % R], M, K, 64) for i in range(R * reps)])
@@ -73,12 +73,11 @@ if what in ("gemv", "all"):
     cold = capture(lambda: [hipabi.gemv(x, packed[i % R], absmax[i % R], M, K, 64) for i in range(R * 2)])
     c, cm = timeit(cold, R * 2)
     print(f"gemv f32 (LDS-x kernel) {M}x{K} cold {c:6.2f} us = {(n // 2 + 4 * (n // 64) + (K + M) * 4) / c / 1e3:6.0f} GB/s", flush=True)
-    for perm in (0, 1):
-        for it in (1, 2, 4, 8):
-            hipabi.set_variant("gemv", (3 << 24) | (perm << 8) | it)
-            cold = capture(lambda: [hipabi.gemv(x, packed[i % R], absmax[i % R], M, K, 64) for i in range(R * 2)])
-            c, cm = timeit(cold, R * 2)
-            print(f"gemv f32 reg-x perm={perm} iters={it} {M}x{K} cold {c:6.2f} us = {(n // 2 + 4 * (n // 64) + (K + M) * 4) / c / 1e3:6.0f} GB/s", flush=True)
+    for it in (1, 2, 4):
+        hipabi.set_variant("gemv", (3 << 24) | it)
+        cold = capture(lambda: [hipabi.gemv(x, packed[i % R], absmax[i % R], M, K, 64) for i in range(R * 2)])
+        c, cm = timeit(cold, R * 2)
+        print(f"gemv f32 reg-x iters={it} {M}x{K} cold {c:6.2f} us = {(n // 2 + 4 * (n // 64) + (K + M) * 4) / c / 1e3:6.0f} GB/s", flush=True)
     hipabi.set_variant("gemv", -1)
     cold = capture(lambda: [hipabi.gemv(x, packed[i % R], absmax[i % R], M, K, 64) for i in range(R * 2)])
     c, cm = timeit(cold, R * 2)
@@ -91,7 +90,7 @@ if what == "regx":
         nbytes = n // 2 + 4 * (n // 64) + (K + M) * isz
         res = []
         for ks in (0, 5, 6, 7, 8):
-            for it in (1, 2, 4, 8):
+            for it in (1, 2, 4):
                 hipabi.set_variant("gemv", (1 << 24) | (ks << 8) | it)
                 try:
                     cold = capture(lambda: [hipabi.gemv(x, packed[i % R], absmax[i % R], M, K, 64) for i in range(R * 2)])

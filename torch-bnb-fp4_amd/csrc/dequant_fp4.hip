@@ -181,12 +181,22 @@ int64_t run_tiles(const uint8_t *packed, const float *absmax, void *out, int bs_
     const int64_t tile = int64_t(kThreads) * loads * kVals;
     const int64_t tiles = n / tile;
     if (tiles == 0) return 0;
-#define FP4_CASE(L)                                                                          \
-    case L:                                                                                  \
-        if (nt)                                                                              \
-            launch_tiles<DT, L, true>(packed, absmax, out, bs_shift, tiles, which_table, stream);    \
-        else                                                                                 \
-            launch_tiles<DT, L, false>(packed, absmax, out, bs_shift, tiles, which_table, stream);   \
+    // Built: f32 output - 1..16 loads per lane, streaming or plain stores; 16-bit output - 1, 2, 4 loads either way and 8 loads with
+    // plain stores (KEEP_CACHED).  (Round 3 removed the 16-bit 8-load streaming and 16-load geometries: sweep-only, behind 4 loads
+    // at every size, profiles/r01_a_sweep_4096x4096.txt.)
+#define FP4_CASE(L)                                                                                   \
+    case L:                                                                                           \
+        if constexpr (DT == FP4_DTYPE_F32 || (L) <= 4) {                                              \
+            if (nt)                                                                                   \
+                launch_tiles<DT, L, true>(packed, absmax, out, bs_shift, tiles, which_table, stream);  \
+            else                                                                                      \
+                launch_tiles<DT, L, false>(packed, absmax, out, bs_shift, tiles, which_table, stream); \
+        } else if constexpr ((L) == 8) {                                                              \
+            if (nt) return -1;                                                                        \
+            launch_tiles<DT, L, false>(packed, absmax, out, bs_shift, tiles, which_table, stream);     \
+        } else {                                                                                      \
+            return -1;                                                                                \
+        }                                                                                             \
         break;
     switch (loads) {
         FP4_CASE(1)

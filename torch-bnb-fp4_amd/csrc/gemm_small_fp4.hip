@@ -573,7 +573,6 @@ __global__ __launch_bounds__(512) void gemm16_mfma_persist_kernel(const uint16_t
 }
 
 std::atomic<int> g_mfma_rowt{-1};     // force 1 or 2 row tiles per workgroup
-std::atomic<int> g_mfma_stage{-1};    // 0 = direct 8-byte weight loads, otherwise LDS-staged 16-byte loads
 std::atomic<int> g_mfma_xstage{-1};   // 0 = B fragments straight from global even for batch <= 8
 std::atomic<int> g_mfma_persist{-1};  // 0 = never the persistent kernel, 1 = whenever it applies
 std::atomic<int> g_mfma_nbw4{-1};     // 1 = at most 4 blocks per wave and pass (pass-ahead loads), 0 = 8 wherever they divide K
@@ -583,7 +582,7 @@ int dispatch_mfma(const void *x, const uint8_t *W, const float *absmax, const vo
                   int K, int mode, hipStream_t stream) {
     if (K % 512) return -1;
     const int units = K / 512;  // quant blocks per wave over the whole K
-    const int v_rowt = g_mfma_rowt.load(std::memory_order_relaxed), v_stage = g_mfma_stage.load(std::memory_order_relaxed),
+    const int v_rowt = g_mfma_rowt.load(std::memory_order_relaxed),
               v_xstage = g_mfma_xstage.load(std::memory_order_relaxed), v_persist = g_mfma_persist.load(std::memory_order_relaxed),
               v_nbw4 = g_mfma_nbw4.load(std::memory_order_relaxed);  // sweep hooks, one snapshot per call
     // Measured (profiles/r01_f_small_batch_shapes.txt): two row tiles per workgroup (x fetched once per 32 rows) only pay
@@ -592,7 +591,7 @@ int dispatch_mfma(const void *x, const uint8_t *W, const float *absmax, const vo
     const unsigned blocks = (unsigned)((M + 16 * rowt - 1) / (16 * rowt));
     // x staged per wave in LDS: always for <= 4 rows (33 KB, two workgroups per CU still fit); for 5..8 rows (66 KB, one
     // workgroup per CU) only while the grid is a single round anyway
-    if (v_persist != 0 && v_rowt <= 0 && v_stage != 0 && v_xstage != 0 && K == 4096) {
+    if (v_persist != 0 && v_rowt <= 0 && v_xstage != 0 && K == 4096) {
         // Up to 4 rows two workgroups fit a CU (78 KB of LDS each), above that one (111 KB of LDS / 166 VGPRs).
         const int ntiles = (M + 15) / 16, resident = (B <= 4 ? 2 : 1) * device_cu_count();
         // measured (profiles/r01_f_small_batch_shapes.txt): never slower than the one-shot kernel, level with it while
@@ -616,19 +615,17 @@ int dispatch_mfma(const void *x, const uint8_t *W, const float *absmax, const vo
     }
     const bool xs4 = v_xstage != 0 && B <= 4;
     const bool xs8 = v_xstage != 0 && !xs4 && B <= 8 && (int)blocks <= device_cu_count();
+    // (round 3: the direct, un-staged 8-byte weight loads - a sweep switch that never won, profiles/r01_e_small_batch_valu_vs_mfma.txt -
+    //  and the <= 4-row x image under two row tiles, which needs > 4 rows to be chosen, are no longer built)
 #define FP4_MF(NBW, RT)                                                                                               \
-    if (v_stage == 0) {                                                                                          \
-        hipLaunchKernelGGL((gemm16_mfma_kernel<DT, NBW, RT, false>), dim3(blocks), dim3(512), 0, stream,              \
-                           reinterpret_cast<const uint16_t *>(x), W, absmax, reinterpret_cast<const uint16_t *>(bias), \
-                           reinterpret_cast<const uint16_t *>(residual), reinterpret_cast<uint16_t *>(out), B, M, K, mode);                                               \
-        return FP4_OK;                                                                                                \
-    }                                                                                                                 \
     if constexpr ((NBW) >= 4) {                                                                                       \
-        if (xs4) {                                                                                                    \
-            hipLaunchKernelGGL((gemm16_mfma_kernel<DT, NBW, RT, true, 4>), dim3(blocks), dim3(512), 0, stream,        \
-                               reinterpret_cast<const uint16_t *>(x), W, absmax,                                      \
-                               reinterpret_cast<const uint16_t *>(bias), reinterpret_cast<const uint16_t *>(residual), reinterpret_cast<uint16_t *>(out), B, M, K, mode); \
-            return FP4_OK;                                                                                            \
+        if constexpr ((RT) == 1) {                                                                                    \
+            if (xs4) {                                                                                                \
+                hipLaunchKernelGGL((gemm16_mfma_kernel<DT, NBW, RT, true, 4>), dim3(blocks), dim3(512), 0, stream,    \
+                                   reinterpret_cast<const uint16_t *>(x), W, absmax,                                  \
+                                   reinterpret_cast<const uint16_t *>(bias), reinterpret_cast<const uint16_t *>(residual), reinterpret_cast<uint16_t *>(out), B, M, K, mode); \
+                return FP4_OK;                                                                                        \
+            }                                                                                                         \
         }                                                                                                             \
         if (xs8) {                                                                                                    \
             hipLaunchKernelGGL((gemm16_mfma_kernel<DT, NBW, RT, true, 8>), dim3(blocks), dim3(512), 0, stream,        \
@@ -706,7 +703,6 @@ void set_small_variant(int v) {
     g_small_variant = v < 0 ? -1 : (v & 1);
     const int rowt = v < 0 ? 0 : ((v >> 4) & 3);  // bits 4-5: row tiles per workgroup of the matrix-core kernel (0 = auto)
     g_mfma_rowt = rowt == 0 ? -1 : rowt;
-    g_mfma_stage = v < 0 ? -1 : ((v >> 8) & 1 ? 0 : 1);  // bit 8: direct (unstaged) weight loads
     g_mfma_xstage = v < 0 ? -1 : ((v >> 9) & 1 ? 0 : 1);  // bit 9: B fragments straight from global
     g_mfma_persist = v < 0 ? -1 : ((v >> 10) & 3) == 1 ? 0 : (((v >> 10) & 3) == 2 ? 1 : -1);  // bits 10-11: 1 = off, 2 = force
     g_mfma_nbw4 = v < 0 ? -1 : ((v >> 14) & 3) == 1 ? 1 : (((v >> 14) & 3) == 2 ? 0 : -1);  // bits 14-15: 1 = 4 blocks per pass, 2 = 8

@@ -566,8 +566,9 @@ int launch32_regx(const void *x, const uint8_t *W, const float *absmax, const vo
 }
 
 // returns -1 when K is too deep for a register-resident f32 x slice (K > 8192): use the LDS kernel
-int dispatch32_regx(bool perm, int iters, const void *x, const uint8_t *W, const float *absmax, const void *bias,
-                    const void *residual, void *out, int M, int K, int bs_shift, hipStream_t stream) {
+// (round 3: the table-free decode - 10 % faster, but outside parity bar 2 in f32 - and 8 row pairs per group are no longer built)
+int dispatch32_regx(int iters, const void *x, const uint8_t *W, const float *absmax, const void *bias, const void *residual, void *out,
+                    int M, int K, int bs_shift, hipStream_t stream) {
     const int C = K >> 5;
     const int ks = C <= 32 ? 1 : (C <= 64 ? 2 : 4);
     if (iters <= 0) {
@@ -577,27 +578,17 @@ int dispatch32_regx(bool perm, int iters, const void *x, const uint8_t *W, const
         iters = 1;
         while (iters < 4 && M / (2 * (4 / ks) * iters * 2) >= 256) iters *= 2;
     }
-#define FP4_R32_IT(KS, GG, PERM)                                                                               \
-    switch (iters) {                                                                                           \
-        case 1: return launch32_regx<KS, GG, 1, PERM>(x, W, absmax, bias, residual, out, M, K, bs_shift, stream);        \
-        case 2: return launch32_regx<KS, GG, 2, PERM>(x, W, absmax, bias, residual, out, M, K, bs_shift, stream);        \
-        case 4: return launch32_regx<KS, GG, 4, PERM>(x, W, absmax, bias, residual, out, M, K, bs_shift, stream);        \
-        default:                                                                                               \
-            if constexpr ((GG) == 1) return launch32_regx<KS, GG, 8, PERM>(x, W, absmax, bias, residual, out, M, K, bs_shift, stream); \
-            return launch32_regx<KS, GG, 4, PERM>(x, W, absmax, bias, residual, out, M, K, bs_shift, stream);            \
-    }
-#define FP4_R32(KS, GG)          \
-    if (perm) {                  \
-        FP4_R32_IT(KS, GG, true) \
-    } else {                     \
-        FP4_R32_IT(KS, GG, false) \
+#define FP4_R32(KS, GG)                                                                                                   \
+    switch (iters) {                                                                                                      \
+        case 1: return launch32_regx<KS, GG, 1, false>(x, W, absmax, bias, residual, out, M, K, bs_shift, stream);        \
+        case 2: return launch32_regx<KS, GG, 2, false>(x, W, absmax, bias, residual, out, M, K, bs_shift, stream);        \
+        default: return launch32_regx<KS, GG, 4, false>(x, W, absmax, bias, residual, out, M, K, bs_shift, stream);       \
     }
     if (C <= 32) { FP4_R32(1, 1) }
     if (C <= 64) { FP4_R32(2, 1) }
     if (C <= 128) { FP4_R32(4, 1) }
-    if (C <= 256) { if (iters > 4) iters = 4; FP4_R32(4, 2) }
+    if (C <= 256) { FP4_R32(4, 2) }
 #undef FP4_R32
-#undef FP4_R32_IT
     return -1;
 }
 
@@ -640,7 +631,7 @@ __global__ __launch_bounds__(256) void gemv_generic_kernel(const void *__restric
     }
 }
 
-// LDS geometry: ROWS | WAVES << 8 | UNROLL << 16; register-x geometry: 1 << 24 | KSPLIT_override << 8 | ITERS; -1 = heuristic.
+// LDS geometry: ROWS | WAVES << 8 | UNROLL << 16; register-x geometry: 1 << 24 | bands (0, 5, 6, 7, 8) << 8 | ITERS; -1 = heuristic.
 // Sweep hook only (fp4_hip_set_variant); relaxed atomic so that a server thread launching while a sweep flips it is not a data race.
 std::atomic<int> g_gemv_variant{-1};
 
@@ -690,7 +681,10 @@ int dispatch16(int variant, const GemvArgs &a) {
 #define FP4_V(R, Wv, U)                  \
     case (R | (Wv << 8) | (U << 16)):    \
         return launch16<DT, R, Wv, U>(a);
-        FP4_V(1, 4, 1) FP4_V(1, 4, 2) FP4_V(2, 4, 2) FP4_V(1, 8, 2) FP4_V(2, 8, 2) FP4_V(1, 16, 2)
+        // (1, 8, 2) is what K > 16384 falls back to; (1, 4, 2) is the north-star mapping at the reference's 4 rows per block.
+        // Round 3 removed (1,4,1) (2,4,2) (2,8,2) (1,16,2): sweep-only, behind the register-x geometry at every measured shape
+        // (profiles/r01_b_exp_gemv_geometries.txt, profiles/r03_kernel_inventory.txt)
+        FP4_V(1, 4, 2) FP4_V(1, 8, 2)
 #undef FP4_V
         default:
             set_error("fp4_hip_gemv: unknown kernel variant 0x%x", variant);
@@ -711,40 +705,25 @@ int launch_regx(const GemvArgs &a) {
     return FP4_OK;
 }
 
-// K decides the band split and the x-slice depth; ITERS (row pairs per group) is the tunable.  `ks_override`
-// (sweeps only) forces KSPLIT; G follows from ceil(C / (32 * KSPLIT)).
+// K decides the band split and the x-slice depth; ITERS (row pairs per group) is the tunable.  `ks_override` selects the
+// 5 / 6 / 7 / 8-band geometries for the row lengths they were built for; G follows from ceil(C / (32 * KSPLIT)).
 template <int DT>
 int dispatch_regx(int iters, int ks_override, const GemvArgs &a) {
     const int C = a.K >> 5;
     if (int64_t(a.M) * a.K >= (int64_t(1) << 32)) return -1;  // 32-bit buffer offsets; the LDS geometry addresses with 64 bits
-    if (ks_override == 8 && C > 64 && C <= 128) {  // sweep hook: 8 waves per workgroup (two row-pair groups)
-        if (iters == 1) return launch_regx<DT, 4, 1, 1, 8>(a);
-        if (iters == 2) return launch_regx<DT, 4, 1, 2, 8>(a);
-        if (iters == 4) return launch_regx<DT, 4, 1, 4, 8>(a);
-    }
     // K = 7 * 1024 * {1, 2, 4} (7168, 14336, 28672 - the Llama-3 / Mistral intermediate sizes): seven waves split the row into
     // seven bands, so no lane of a 32-chunk band is idle (4 bands leave an eighth of the deepest slice dead at 14336) and
     // 28672 still fits the register-resident x slice
+    // Only the (depth, row pairs) the heuristic picks are built (round 3: the other ITERS lost every sweep,
+    // profiles/r01_f_gemv_seven_bands.txt, profiles/r02_gemv_regx_sweep.txt): 7168 -> 2 row pairs, 14336 -> 4, 28672 -> 2.
     if (ks_override == 7 && C % 224 == 0 && (C / 224 == 1 || C / 224 == 2 || C / 224 == 4)) {
         const int g7 = C / 224;
-        if (g7 == 4 && iters > 2) iters = 2;
-        if (iters > 4) iters = 4;  // (8 row pairs per workgroup measured slower: 9.8 vs 9.0 us at 4096 x 14336, profiles/r02_gemv_regx_sweep.txt)
-#define FP4_RX7(GG)                                                                                                   \
-    switch (iters) {                                                                                                  \
-        case 1: return launch_regx<DT, 7, GG, 1, 7>(a);        \
-        case 2: return launch_regx<DT, 7, GG, 2, 7>(a);        \
-        default: return launch_regx<DT, 7, GG, 4, 7>(a);       \
-    }
-        if (g7 == 1) { FP4_RX7(1) }
-        if (g7 == 2) { FP4_RX7(2) }
-        switch (iters) {
-            case 1: return launch_regx<DT, 7, 4, 1, 7>(a);
-            default: return launch_regx<DT, 7, 4, 2, 7>(a);
-        }
-#undef FP4_RX7
+        if (g7 == 1) return launch_regx<DT, 7, 1, 2, 7>(a);
+        if (g7 == 2) return launch_regx<DT, 7, 2, 4, 7>(a);
+        return launch_regx<DT, 7, 4, 2, 7>(a);
     }
     // five / six bands for rows of exactly 5 or 6 (x 1, 2) band widths: K = 5120 / 10240 (Llama-2-13B hidden size) and 6144 / 12288
-    if ((ks_override == 5 && C % 160 == 0 && C / 160 <= 2) || (ks_override == 6 && C % 192 == 0 && C / 192 <= 2)) {
+    if ((ks_override == 5 && C % 160 == 0 && C / 160 <= 2) || (ks_override == 6 && C == 192)) {
         const int gg = C / (32 * ks_override);
         if (iters > 4) iters = 4;
 #define FP4_RXN(KS, GG)                                                                                               \
@@ -756,35 +735,24 @@ int dispatch_regx(int iters, int ks_override, const GemvArgs &a) {
         if (ks_override == 5 && gg == 1) { FP4_RXN(5, 1) }
         if (ks_override == 5 && gg == 2) { FP4_RXN(5, 2) }
         if (ks_override == 6 && gg == 1) { FP4_RXN(6, 1) }
-        if (ks_override == 6 && gg == 2) { FP4_RXN(6, 2) }
 #undef FP4_RXN
     }
-    if (ks_override == 8 && C > 128) {  // K split 8 ways over 8 waves: the default for K = 8192, a sweep hook elsewhere
-        const int need8 = (C + 255) / 256;
-        if (need8 <= 1) {
-            if (iters == 1) return launch_regx<DT, 8, 1, 1, 8>(a);
-            if (iters == 2) return launch_regx<DT, 8, 1, 2, 8>(a);
-            return launch_regx<DT, 8, 1, 4, 8>(a);
-        } else if (need8 <= 2) {
-            if (iters == 1) return launch_regx<DT, 8, 2, 1, 8>(a);
-            if (iters == 2) return launch_regx<DT, 8, 2, 2, 8>(a);
-            return launch_regx<DT, 8, 2, 4, 8>(a);
-        } else if (need8 <= 4) {
-            if (iters == 1) return launch_regx<DT, 8, 4, 1, 8>(a);
-            return launch_regx<DT, 8, 4, 2, 8>(a);
-        }
-        return -1;
+    if (ks_override == 8 && C == 256) {  // K = 8192 split 8 ways over 8 waves (the heuristic's choice from 4096 rows up)
+        if (iters >= 4) return launch_regx<DT, 8, 1, 4, 8>(a);
+        return launch_regx<DT, 8, 1, 2, 8>(a);
     }
-    int ks = C <= 32 ? 1 : (C <= 64 ? 2 : 4);
-    if (ks_override == 1 || ks_override == 2 || ks_override == 4) ks = ks_override;
+    const int ks = C <= 32 ? 1 : (C <= 64 ? 2 : 4);
     const int need = (C + 32 * ks - 1) / (32 * ks);
     // (a 3-deep slice only with the 4-way split: K = 11008, the Llama-2 down-projection, would waste a third of a 4-deep one)
     const int g = need <= 1 ? 1 : (need <= 2 ? 2 : ((need == 3 && ks == 4) ? 3 : (need <= 4 ? 4 : 0)));
     if (g == 0) return -1;  // the x slice no longer fits the register budget; use the LDS geometry
-    if (g == 2 && iters > 4) iters = 4;
+    if (iters > 4) iters = 4;
     if (g >= 3 && iters > 2) iters = 2;
+    if (iters == 3) iters = 2;
+    if (iters < 1) iters = 1;
 #define FP4_RX(KS, GG, IT) return launch_regx<DT, KS, GG, IT>(a)
-    // only the (G, ITERS) pairs the clamps above let through are instantiated: G = 1 -> 1, 2, 4, 8; G = 2 -> 1, 2, 4; G >= 3 -> 1, 2
+    // only the (KSPLIT, G, ITERS) triples the heuristic can reach are instantiated: the split follows K, G = 1, 2 -> 1, 2, 4 row pairs;
+    // G >= 3 -> 1, 2 (round 3 removed 8 row pairs and the forced splits with deep slices: sweep-only, never ahead)
 #define FP4_RX_IT(KS, GG)                                    \
     if (ks == KS && g == GG) {                               \
         switch (iters) {                                     \
@@ -793,14 +761,10 @@ int dispatch_regx(int iters, int ks_override, const GemvArgs &a) {
             case 4:                                          \
                 if constexpr ((GG) <= 2) { FP4_RX(KS, GG, 4); } \
                 break;                                       \
-            case 8:                                          \
-                if constexpr ((GG) == 1) { FP4_RX(KS, GG, 8); } \
-                break;                                       \
             default: break;                                  \
         }                                                    \
     }
-    FP4_RX_IT(1, 1) FP4_RX_IT(1, 2) FP4_RX_IT(1, 4) FP4_RX_IT(2, 1) FP4_RX_IT(2, 2) FP4_RX_IT(2, 4) FP4_RX_IT(4, 1) FP4_RX_IT(4, 2)
-    FP4_RX_IT(4, 3) FP4_RX_IT(4, 4)
+    FP4_RX_IT(1, 1) FP4_RX_IT(2, 1) FP4_RX_IT(4, 1) FP4_RX_IT(4, 2) FP4_RX_IT(4, 3) FP4_RX_IT(4, 4)
 #undef FP4_RX_IT
 #undef FP4_RX
     set_error("fp4_hip_gemv: unknown regx geometry (iters %d, ksplit %d, g %d)", iters, ks, g);
@@ -902,10 +866,9 @@ int gemv_entry(const void *x, const uint8_t *packed, const float *absmax, const 
     } else if (mode & kModeSiluMulPairs) {
         rc = -2;  // f32 activations / irregular shapes: only the register-x geometry pairs rows up
     } else if (fast && gv != 0 &&
-               // default: the bit-faithful CODE_PARAM f32 table (the all-f32 reference kernel is accurate to ~1e-7, so the
-               // table's 1e-6 deviations from k/12 are visible at f32); variant bit 8 selects the table-free decode (+10 %)
-               dispatch32_regx(gv >= 0 && ((gv >> 8) & 1), gv < 0 ? 0 : (gv & 0xFF), x, packed, absmax, bias, residual, out, (int)M,
-                               (int)K, bs_shift, s) == FP4_OK) {
+               // the bit-faithful CODE_PARAM f32 table (the all-f32 reference kernel is accurate to ~1e-7, so the table's 1e-6
+               // deviations from k/12 are visible at f32)
+               dispatch32_regx(gv < 0 ? 0 : (gv & 0xFF), x, packed, absmax, bias, residual, out, (int)M, (int)K, bs_shift, s) == FP4_OK) {
         rc = FP4_OK;  // f32 activations, register-x geometry (variant 0 forces the LDS kernel below, for sweeps)
     } else if (fast) {
         auto kern = gemv32_kernel<1, 4>;
