@@ -308,6 +308,7 @@ def c5_leg(dist, backend, rank, world, dev, barrier, tokens=16):
 
                 st = par.oneshot_comm(None).status()
                 out[ar]["timeouts"] = int(st[3])  # lanes that gave up waiting for a peer (must be 0 for the figure to count)
+                par.check_oneshot(None)  # raises (-> "error" below) if any reduction of the leg timed out: its outputs were NaN
             out["allreduces_per_token"] = meta["allreduces_per_token"]
             out["fp4_bytes_per_token_per_gpu"] = meta["fp4_bytes_per_token_per_gpu"]
             del token, h0

@@ -337,6 +337,77 @@ def test_bitsandbytes_format_roundtrip(tmp_path):
         P.fp4_linear_from_bnb_state(bad, "a.")
 
 
+def test_fused_gated_mlp_saves_as_its_two_projections_and_casts_keep_the_scales(tmp_path):
+    """fuse_gated_mlps followed by the usual model.to(dtype) must not touch the f32 scales (FusedFP4Linear._apply honours device
+    moves only); save_fp4_model writes the interleaved gate|up weight back as the two bitsandbytes-layout projections, so the file
+    loads into a fresh UNFUSED model (bit-identical layers), which can be fused again; tensors the model has no place for are an
+    error, not a silent drop."""
+    P = pkg()
+    from safetensors.torch import load_file, save_file
+
+    from torch_bnb_fp4.surgery import FusedGatedMLP
+
+    class MLP(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.gate_proj, self.up_proj, self.down_proj = nn.Linear(256, 704, bias=False), nn.Linear(256, 704, bias=False), nn.Linear(704, 256, bias=False)
+            self.act_fn = nn.SiLU()
+
+        def forward(self, x):
+            return self.down_proj(self.act_fn(self.gate_proj(x)) * self.up_proj(x))
+
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.mlp = MLP()
+            self.norm = nn.LayerNorm(256)
+
+        def forward(self, x):
+            return self.norm(x + self.mlp(x))
+
+    torch.manual_seed(21)
+    net = P.recursively_replace_with_fp4_linear(Net().to(dev()), device=dev())
+    x = torch.randn(1, 256, device=dev(), dtype=torch.bfloat16)
+    gate_bits, gate_scales = net.mlp.gate_proj.qweight.clone(), net.mlp.gate_proj.absmax.clone()
+    up_bits, up_scales = net.mlp.up_proj.qweight.clone(), net.mlp.up_proj.absmax.clone()
+    net.norm.to(torch.bfloat16)
+    y_unfused = net(x)
+    assert P.fuse_gated_mlps(net) == 1 and isinstance(net.mlp, FusedGatedMLP)
+    scales = net.mlp.gate_up.absmax.clone()
+    net.to(torch.bfloat16)
+    net.half().to(torch.bfloat16)
+    assert net.mlp.gate_up.absmax.dtype == torch.float32 and torch.equal(net.mlp.gate_up.absmax, scales)
+    assert net.mlp.gate_up.quant_data.absmax.data_ptr() == net.mlp.gate_up.absmax.data_ptr()
+    y_fused = net(x)
+    assert (y_fused.float() - y_unfused.float()).abs().max() <= 0.02 * y_unfused.float().abs().max() + 1e-2
+    path = str(tmp_path / "fused.safetensors")
+    P.save_fp4_model(net, path)
+    keys = set(load_file(path))
+    assert {"mlp.gate_proj.weight", "mlp.gate_proj.weight.absmax", "mlp.up_proj.weight", "mlp.up_proj.weight.quant_state.bitsandbytes__fp4",
+            "mlp.down_proj.weight"} <= keys and not any("gate_up" in k for k in keys)
+    fresh = Net().to(dev())
+    fresh.norm.to(torch.bfloat16)
+    fresh = P.load_fp4_layers(fresh, path, device=dev())
+    assert isinstance(fresh.mlp.gate_proj, P.TorchFP4Linear) and isinstance(fresh.mlp.up_proj, P.TorchFP4Linear)
+    assert torch.equal(fresh.mlp.gate_proj.qweight, gate_bits) and torch.equal(fresh.mlp.gate_proj.absmax, gate_scales)
+    assert torch.equal(fresh.mlp.up_proj.qweight, up_bits) and torch.equal(fresh.mlp.up_proj.absmax, up_scales)
+    assert torch.equal(fresh(x), y_unfused)
+    assert P.fuse_gated_mlps(fresh) == 1 and torch.equal(fresh(x), y_fused)
+    # a file holding tensors the model has no place for is refused (strict) or reported (strict=False)
+    extra = dict(load_file(path))
+    extra["mlp.gate_up.qweight"] = torch.zeros(4, dtype=torch.uint8)
+    bad = str(tmp_path / "stale.safetensors")
+    save_file(extra, bad)
+    with pytest.raises(KeyError, match="gate_up"):
+        P.load_fp4_layers(Net().to(dev()), bad, device=dev())
+    lenient = P.load_fp4_layers(Net().to(dev()), bad, device=dev(), strict=False)
+    assert lenient.fp4_unexpected_keys == ["mlp.gate_up.qweight"]
+    # a gate|up layer outside a FusedGatedMLP has no names to be saved under
+    lone = nn.Sequential(net.mlp.gate_up)
+    with pytest.raises(ValueError, match="two projections"):
+        P.save_fp4_model(lone, str(tmp_path / "lone.safetensors"))
+
+
 def test_hip_graph_capture_and_replay_of_the_linear_shell():
     """Every op on the path is capturable (no allocation in the C ABI, current-stream launches): a decode step
     captured once replays correctly on new inputs (the reference's legacy-stream launches could not be captured)."""

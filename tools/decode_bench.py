@@ -238,6 +238,11 @@ def main():
                     barrier=barrier)
     if t["graph_error"] and rank == 0:
         print("graph capture failed:", t["graph_error"], file=sys.stderr)
+    if world > 1 and args.allreduce == "oneshot":
+        # sync point outside capture: a reduction that timed out waiting for a peer wrote NaN - the figure must not be reported
+        from torch_bnb_fp4 import parallel as par
+
+        par.check_oneshot(None)
     if rank == 0:
         best = t["graph_s"] or t["eager_s"]
         per_token_fp4 = meta["fp4_bytes_per_token_per_gpu"]

@@ -23,11 +23,30 @@ from .dtypes import ScalarType
 _KINDS = {0: "uncached", 1: "fine-grained", 2: "default"}
 
 
+def _device_identity(device: torch.device) -> str:
+    """Something that tells two GPUs of one node apart (for "do my peers sit on other devices?")."""
+    props = torch.cuda.get_device_properties(device)
+    uuid = getattr(props, "uuid", None)
+    return str(uuid) if uuid is not None else f"{os.uname().nodename}:{device.index}:{getattr(props, 'pci_bus_id', '')}"
+
+
 class OneShotAllReduce:
+    """Launch-time requirement: ``HSA_ENABLE_IPC_MODE_LEGACY=0`` must be in the environment BEFORE the process starts (the host
+    driver only supports dmabuf IPC; the HIP runtime reads the variable when it initialises, so setting it here would be too late).
+
+    Memory: the slot buffer is written by peers, so it is allocated uncached (or fine-grained) where the runtime offers it.  If
+    only plain ``hipMalloc`` memory is available (``memory_kind == "default"``) AND a peer sits on another device, the owner's L2
+    may serve stale lines for peer-written slots: the tag-in-granule design turns that into time-outs and NaN rather than wrong
+    sums, but the path is refused unless ``FP4_COMM_ALLOC=default`` asks for it explicitly."""
+
     def __init__(self, group=None, capacity: int = 16384, device: Optional[torch.device] = None, timeout_us: int = 2_000_000):
         if not dist.is_initialized():
             raise RuntimeError("OneShotAllReduce needs an initialised torch.distributed process group")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the host driver only supports dmabuf IPC
+        if os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY") != "0":
+            import warnings
+
+            warnings.warn("OneShotAllReduce: HSA_ENABLE_IPC_MODE_LEGACY=0 is not in this process's environment; it has to be exported "
+                          "before the process starts, or hipIpcGetMemHandle / hipIpcOpenMemHandle fail with 'invalid argument'")
         self.group = group
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         self.capacity = int(capacity)
@@ -36,9 +55,18 @@ class OneShotAllReduce:
         self._own, handle, kind = ext.comm_alloc(self.world, self.capacity, self.device.index)
         self.memory_kind = _KINDS.get(kind, str(kind))
         handles = [None] * self.world
-        dist.all_gather_object(handles, (self.rank, os.getpid(), bytes(handle)), group=group)
+        dist.all_gather_object(handles, (self.rank, os.getpid(), bytes(handle), _device_identity(self.device), self.memory_kind), group=group)
+        other_devices = sorted({r for r, _, _, ident, _ in handles if ident != _device_identity(self.device)})
+        plain = sorted({r for r, _, _, _, k in handles if k == "default"})
+        if other_devices and plain and os.environ.get("FP4_COMM_ALLOC") != "default":
+            ext.comm_free(self._own)
+            self._own = None
+            raise RuntimeError(f"OneShotAllReduce: rank(s) {plain} could only allocate plain device memory (memory_kind 'default'; this rank: "
+                               f"'{self.memory_kind}') and the group spans several devices (peers of rank {self.rank} on other devices: "
+                               f"{other_devices}): peer-written slots may be served stale from the owner's L2.  Use allreduce='dist' "
+                               "(RCCL), or set FP4_COMM_ALLOC=default to accept time-outs / NaN as the failure mode")
         self._peers, self._opened = [], []
-        for r, pid, h in handles:
+        for r, pid, h, _, _ in handles:
             if r == self.rank:
                 self._peers.append(self._own)
             elif pid == os.getpid():

@@ -45,6 +45,19 @@ def interleave_rows(a: Tuple[torch.Tensor, torch.Tensor], b: Tuple[torch.Tensor,
     return packed, absmax, (2 * M, K)
 
 
+def deinterleave_rows(packed: torch.Tensor, absmax: torch.Tensor, shape: Sequence[int], blocksize: int):
+    """Inverse of :func:`interleave_rows`: the even rows and the odd rows of a ``[2M, K]`` FP4 weight as two ``[M, K]`` weights,
+    ``((packed_a, absmax_a), (packed_b, absmax_b), (M, K))`` - what a checkpoint in bitsandbytes' layout stores for a gate and an
+    up projection."""
+    M2, K = int(shape[0]), int(shape[1])
+    if M2 % 2 or K % blocksize or K % 2:
+        raise ValueError(f"deinterleave_rows needs an even row count and in_features ({K}) divisible by the blocksize ({blocksize})")
+    p = packed.reshape(M2 // 2, 2, K // 2)
+    a = absmax.reshape(M2 // 2, 2, K // blocksize)
+    return ((p[:, 0].reshape(-1, 1).contiguous(), a[:, 0].reshape(-1).contiguous()),
+            (p[:, 1].reshape(-1, 1).contiguous(), a[:, 1].reshape(-1).contiguous()), (M2 // 2, K))
+
+
 class FusedFP4Linear(nn.Module):
     """An FP4 Linear whose single-token path runs ``fp4_hip_gemv_fused``.
 

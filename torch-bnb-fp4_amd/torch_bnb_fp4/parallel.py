@@ -85,17 +85,38 @@ def _all_gather_last(y: torch.Tensor, world: int, group) -> torch.Tensor:
 
 
 _COMMS = {}
+ONESHOT_CAPACITY = 65536  # elements: the largest partial RowParallelFP4Linear sends through the one-shot path (8 MiB of slots at G = 8)
 
 
-def oneshot_comm(group=None, capacity: int = 16384):
-    """The process group's shared :class:`~torch_bnb_fp4.comm.OneShotAllReduce` (created on first use: a collective call)."""
+def oneshot_comm(group=None, capacity: int = ONESHOT_CAPACITY):
+    """The process group's shared :class:`~torch_bnb_fp4.comm.OneShotAllReduce`, created on first use (a COLLECTIVE call: every
+    rank must reach it together, outside any HIP-graph capture) and sized once for the path's own limit - it is never re-created
+    behind the caller's back (a regrow would run collectives, an allocation and a device synchronisation inside ``forward``)."""
     from .comm import OneShotAllReduce
 
-    key = (id(group) if group is not None else None, torch.cuda.current_device())
+    key = (group, torch.cuda.current_device())  # the group object itself (id() values are recycled after GC)
     comm = _COMMS.get(key)
-    if comm is None or comm.capacity < capacity:
-        comm = _COMMS[key] = OneShotAllReduce(group, capacity=max(capacity, 16384))
+    if comm is None:
+        comm = _COMMS[key] = OneShotAllReduce(group, capacity=max(int(capacity), ONESHOT_CAPACITY))
+    elif comm.capacity < capacity:
+        raise ValueError(f"oneshot_comm: {capacity} elements exceed the communicator's capacity of {comm.capacity}; larger partials go "
+                         "through torch.distributed (allreduce='dist')")
     return comm
+
+
+def check_oneshot(group=None) -> None:
+    """Synchronous health check of the group's one-shot communicator, for a sync point of the decode loop OUTSIDE graph capture:
+    raises if a reduction timed out waiting for a peer since the last check (its outputs were NaN).  No-op if none exists yet."""
+    comm = _COMMS.get((group, torch.cuda.current_device()))
+    if comm is not None:
+        comm.check()
+
+
+def close_oneshot(group=None) -> None:
+    """Release the group's one-shot communicator (collective: peers unmap each other's buffers after a barrier)."""
+    comm = _COMMS.pop((group, torch.cuda.current_device()), None)
+    if comm is not None:
+        comm.close()
 
 
 def _quant_data(packed, absmax, shape, blocksize, bias, use_codebook_dequant=True) -> QuantData:
@@ -158,6 +179,8 @@ class FusedColumnParallelFP4(nn.Module):
 class RowParallelFP4Linear(nn.Module):
     """K-split: this rank owns ``in_features / world`` columns; outputs are summed across ranks in f32."""
 
+    _mm_f32_out = True  # cleared the first time torch.mm(..., out_dtype=float32) turns out not to exist in this build
+
     def __init__(self, packed, absmax, shape, blocksize: int = 64, bias: Optional[torch.Tensor] = None, group=None,
                  input_is_parallel: bool = False, allreduce: str = "dist"):
         super().__init__()
@@ -174,6 +197,12 @@ class RowParallelFP4Linear(nn.Module):
         self.input_is_parallel = input_is_parallel
         self.out_features, self.in_features = int(shape[0]), int(shape[1])
 
+    def check(self) -> None:
+        """Raise if a one-shot reduction of this layer's group timed out since the last check (synchronises the device; call it at
+        a sync point of the decode loop, never inside graph capture).  ``allreduce="dist"`` has nothing to check."""
+        if self.allreduce == "oneshot":
+            check_oneshot(self.group)
+
     def forward(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
         ks = self.local_shape[1]
         xs = x if self.input_is_parallel else x[..., self.rank * ks:(self.rank + 1) * ks]
@@ -182,15 +211,31 @@ class RowParallelFP4Linear(nn.Module):
         if single:  # single token: fused GEMV, raw f32 accumulator out
             part = ext.gemv_fp4_partial(xs.reshape(1, ks).contiguous(), qd.A.t(), qd.absmax, self.blocksize, list(self.local_shape))
             part = part.view(*x.shape[:-1], self.out_features)
-        else:  # batch / sequence: dequantise to f32 and multiply in f32, so the partial carries no rounding to T
+        else:
+            # batch / sequence: the reference's batch semantics (dequantise to the activation dtype, then a dense GEMM,
+            # torch_bnb_fp4/__init__.py:423-436) with the shard's product kept in f32 - 16-bit operands on the matrix cores, f32
+            # accumulation AND f32 output (aten::mm.dtype), so the partial is not rounded to T before the ranks are summed.  (Round 2
+            # dequantised the shard to f32 and multiplied in f32: twice the transient weight and the far slower f32 GEMM at prefill
+            # sizes.)  f32 activations, or a build without the f32-output GEMM, take that f32 path.
             if not qd.compute_dtype_set:
                 qd.set_compute_type(xs)
-            w32 = ext.dequantize_fp4_codebook(qd.A, qd.absmax, qd.code, qd.M, qd.N, qd.blocksize, qd.numel, ScalarType.float32.value)
-            part = torch.nn.functional.linear(xs.float(), w32)
-        if self.world > 1 and self.allreduce == "oneshot" and part.is_cuda and part.numel() <= 65536:
+            x2 = xs.reshape(-1, ks)
+            part = None
+            if x2.dtype in (torch.float16, torch.bfloat16) and RowParallelFP4Linear._mm_f32_out:
+                w16 = ext.dequantize_fp4_codebook(qd.A, qd.absmax, qd.code, qd.M, qd.N, qd.blocksize, qd.numel,
+                                                  ScalarType.from_torch_dtype(x2.dtype).value)
+                try:
+                    part = torch.mm(x2, w16.t(), out_dtype=torch.float32)
+                except (NotImplementedError, RuntimeError, TypeError):
+                    RowParallelFP4Linear._mm_f32_out = False
+            if part is None:
+                w32 = ext.dequantize_fp4_codebook(qd.A, qd.absmax, qd.code, qd.M, qd.N, qd.blocksize, qd.numel, ScalarType.float32.value)
+                part = torch.nn.functional.linear(x2.float(), w32)
+            part = part.view(*x.shape[:-1], self.out_features)
+        if self.world > 1 and self.allreduce == "oneshot" and part.is_cuda and part.numel() <= ONESHOT_CAPACITY:
             # (latency-bound sizes only: decode and small batches; a prefill-sized partial goes through torch.distributed below)
             # one launch: publish into every peer's slots, gather, sum in rank order, round once, bias / residual on top
-            comm = oneshot_comm(self.group, part.numel())
+            comm = oneshot_comm(self.group)
             bias = None if self.bias is None else self.bias.to(x.dtype)
             if bias is not None and part.numel() != self.out_features:
                 bias = bias.expand(part.shape).contiguous()

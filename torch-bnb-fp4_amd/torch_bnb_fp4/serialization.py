@@ -35,19 +35,43 @@ def _unpack_json(t: torch.Tensor) -> dict:
     return json.loads(bytes(t.detach().cpu().to(torch.uint8).tolist()).decode("utf-8"))
 
 
+def _bnb_entries(prefix: str, packed, absmax, code, blocksize: int, shape, dtype, bias) -> Dict[str, torch.Tensor]:
+    meta = {"quant_type": "fp4", "blocksize": int(blocksize), "dtype": str(dtype).replace("torch.", ""), "shape": [int(shape[0]), int(shape[1])]}
+    out = {
+        prefix + "weight": packed.detach().cpu().reshape(-1, 1),
+        prefix + "weight.absmax": absmax.detach().float().cpu(),
+        prefix + "weight.quant_map": code.detach().float().cpu(),
+        prefix + _STATE_KEY: _pack_json(meta),
+    }
+    if bias is not None:
+        out[prefix + "bias"] = bias.detach().cpu()
+    return out
+
+
 def fp4_linear_to_bnb_state(layer: TorchFP4Linear, prefix: str = "") -> Dict[str, torch.Tensor]:
     """State-dict entries of one layer in bitsandbytes' 4-bit layout (tensors moved to the CPU)."""
     qd = layer.quant_data
-    meta = {"quant_type": "fp4", "blocksize": int(qd.blocksize), "dtype": str(qd.quant_state.dtype).replace("torch.", ""),
-            "shape": [int(qd.M), int(qd.N)]}
-    out = {
-        prefix + "weight": qd.A.detach().cpu().reshape(-1, 1),
-        prefix + "weight.absmax": qd.absmax.detach().cpu(),
-        prefix + "weight.quant_map": qd.code.detach().cpu(),
-        prefix + _STATE_KEY: _pack_json(meta),
-    }
-    if layer.bias is not None:
-        out[prefix + "bias"] = layer.bias.detach().cpu()
+    return _bnb_entries(prefix, qd.A, qd.absmax, qd.code, qd.blocksize, (qd.M, qd.N), qd.quant_state.dtype, layer.bias)
+
+
+def fused_linear_to_bnb_state(layer, prefix: str = "", pair_prefixes=None, dtype=torch.float16) -> Dict[str, torch.Tensor]:
+    """A :class:`~torch_bnb_fp4.fused.FusedFP4Linear` in bitsandbytes' layout.  A plain one (residual epilogue) is one entry under
+    ``prefix``; a gate|up one is DE-INTERLEAVED into the two projections it was built from and written under ``pair_prefixes``
+    (the rows are a load-time permutation of the bnb bytes, not a new format) - without names for the pair it cannot be saved."""
+    from .fused import EPILOGUE_SILU_MUL_PAIRS, deinterleave_rows
+
+    qd = layer.quant_data
+    if layer.epilogue != EPILOGUE_SILU_MUL_PAIRS:
+        return _bnb_entries(prefix, qd.A, qd.absmax, qd.code, qd.blocksize, (qd.M, qd.N), dtype, layer.bias)
+    if not pair_prefixes:
+        raise ValueError(f"{prefix or 'layer'}: a gate|up FusedFP4Linear can only be saved as its two projections; it is not inside a "
+                         "FusedGatedMLP that remembers their names - save the unfused model (before fuse_gated_mlps) instead")
+    (pg, ag), (pu, au), shape = deinterleave_rows(qd.A, qd.absmax, (qd.M, qd.N), qd.blocksize)
+    bias = layer.bias
+    bg = None if bias is None else bias.reshape(-1, 2)[:, 0].contiguous()
+    bu = None if bias is None else bias.reshape(-1, 2)[:, 1].contiguous()
+    out = _bnb_entries(pair_prefixes[0], pg, ag, qd.code, qd.blocksize, shape, dtype, bg)
+    out.update(_bnb_entries(pair_prefixes[1], pu, au, qd.code, qd.blocksize, shape, dtype, bu))
     return out
 
 
@@ -79,26 +103,45 @@ def fp4_linear_from_bnb_state(state: Mapping[str, torch.Tensor], prefix: str = "
 
 
 def save_fp4_model(model: torch.nn.Module, path: str) -> None:
-    """Write every :class:`TorchFP4Linear` of ``model`` (bitsandbytes layout) and every other tensor of its
-    ``state_dict`` to one safetensors file."""
+    """Write every FP4 layer of ``model`` (bitsandbytes layout) and every other tensor of its ``state_dict`` to one safetensors
+    file.  :class:`TorchFP4Linear` layers are written as they are; the fused layers of :mod:`torch_bnb_fp4.fused` are written as
+    the plain projections they were built from (a gated MLP's interleaved gate|up weight is de-interleaved under the two names
+    the unfused model uses), so the file always loads into a fresh, UNFUSED model with :func:`load_fp4_layers` - after which
+    ``fuse_gated_mlps`` can be applied again.  A fused layer that cannot be expressed that way raises instead of being written as
+    tensors no loader would recognise."""
     from safetensors.torch import save_file
+
+    from .fused import FusedFP4Linear
+    from .surgery import FusedGatedMLP
 
     tensors: Dict[str, torch.Tensor] = {}
     fp4_prefixes = []
+    gated = {}  # prefix of a FusedGatedMLP's gate_up child -> (prefix for gate, prefix for up, dtype)
     for name, mod in model.named_modules():
+        if isinstance(mod, FusedGatedMLP):
+            base = name + "." if name else ""
+            gated[base + "gate_up."] = (base + mod.projection_names[0] + ".", base + mod.projection_names[1] + ".", mod.quant_dtype)
+    for name, mod in model.named_modules():
+        prefix = name + "." if name else ""
         if isinstance(mod, TorchFP4Linear):
-            prefix = name + "." if name else ""
             fp4_prefixes.append(prefix)
             tensors.update(fp4_linear_to_bnb_state(mod, prefix))
+        elif isinstance(mod, FusedFP4Linear):
+            fp4_prefixes.append(prefix)
+            g = gated.get(prefix)
+            tensors.update(fused_linear_to_bnb_state(mod, prefix, None if g is None else g[:2], torch.float16 if g is None else g[2]))
     for key, val in model.state_dict().items():
         if not any(key.startswith(p) for p in fp4_prefixes):
             tensors[key] = val.detach().cpu().contiguous()
     save_file({k: v.contiguous() for k, v in tensors.items()}, path)
 
 
-def load_fp4_layers(model: torch.nn.Module, path: str, device="cuda", use_codebook_dequant: bool = True) -> torch.nn.Module:
+def load_fp4_layers(model: torch.nn.Module, path: str, device="cuda", use_codebook_dequant: bool = True,
+                    strict: bool = True) -> torch.nn.Module:
     """Replace, in ``model``, every ``nn.Linear`` for which ``path`` holds a bitsandbytes FP4 weight by a
-    :class:`TorchFP4Linear` built from the stored bytes; other tensors are loaded with ``load_state_dict(strict=False)``."""
+    :class:`TorchFP4Linear` built from the stored bytes; the file's other tensors are loaded into the model.  Tensors of the
+    file that the model has no place for raise a ``KeyError`` (``strict=False``: they are listed in ``model.fp4_unexpected_keys``
+    instead) - a checkpoint is never half-applied silently."""
     from safetensors.torch import load_file
 
     state = load_file(path)
@@ -114,6 +157,12 @@ def load_fp4_layers(model: torch.nn.Module, path: str, device="cuda", use_codebo
             model = layer
         consumed.update(k for k in state if k.startswith(prefix))
     rest = {k: v for k, v in state.items() if k not in consumed}
+    unexpected = []
     if rest and isinstance(model, torch.nn.Module):
-        model.load_state_dict(rest, strict=False)
+        unexpected = list(model.load_state_dict(rest, strict=False).unexpected_keys)
+    if unexpected and strict:
+        raise KeyError(f"load_fp4_layers: {len(unexpected)} tensor(s) of {path} have no place in the model (saved from a model with a "
+                       f"different structure?): {unexpected[:8]}{' ...' if len(unexpected) > 8 else ''}")
+    if isinstance(model, torch.nn.Module):
+        model.fp4_unexpected_keys = unexpected
     return model

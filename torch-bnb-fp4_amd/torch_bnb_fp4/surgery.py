@@ -148,12 +148,16 @@ class FusedGatedMLP(nn.Module):
     """``down(silu(gate(x)) * up(x))`` with the gate and up projections as ONE launch whose epilogue applies the activation
     and the product (:mod:`torch_bnb_fp4.fused`); what :func:`fuse_gated_mlps` puts in place of a Llama / Mistral style MLP."""
 
-    def __init__(self, gate: TorchFP4Linear, up: TorchFP4Linear, down: nn.Module):
+    def __init__(self, gate: TorchFP4Linear, up: TorchFP4Linear, down: nn.Module, names=("gate_proj", "up_proj")):
         super().__init__()
         from .fused import FusedFP4Linear
 
         self.gate_up = FusedFP4Linear.gate_up(gate, up)
         self.down_proj = down
+        # the two projections' names in the unfused model: save_fp4_model writes the interleaved weight back under them
+        # (bitsandbytes layout, one entry per projection), so that the file loads into a fresh, unfused model
+        self.projection_names = (str(names[0]), str(names[1]))
+        self.quant_dtype = gate.quant_data.quant_state.dtype
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         return self.down_proj(self.gate_up(x))
@@ -171,7 +175,7 @@ def fuse_gated_mlps(module: nn.Module, gate: str = "gate_proj", up: str = "up_pr
         if (isinstance(g, TorchFP4Linear) and isinstance(u, TorchFP4Linear) and isinstance(d, nn.Module) and silu
                 and (g.quant_data.M, g.quant_data.N, g.quant_data.blocksize) == (u.quant_data.M, u.quant_data.N, u.quant_data.blocksize)
                 ):
-            module._modules[name] = FusedGatedMLP(g, u, d)
+            module._modules[name] = FusedGatedMLP(g, u, d, names=(gate, up))
             count += 1
         else:
             count += fuse_gated_mlps(child, gate, up, down, act)
