@@ -622,7 +622,7 @@ def main():
                     "bytes_per_launch": dq_b,
                     "avg_launch_us": round(dq_us, 3),
                     "method": "HIP events around each graph replay of R back-to-back launches on the launch stream; includes one kernel "
-                              "boundary per launch; rocprofv3 trace of this command: profiles/r02_h_bench_kernel_trace_summary.json",
+                              "boundary per launch; rocprofv3 trace of this command: profiles/r03_bench_kernel_trace_summary.json (roofline_rows)",
                 },
                 "roofline_gemv": {
                     "bound": "hbm", "kernel": "gemv16_regx_kernel<bf16> (fp4_hip_gemv)", "achieved": round(gv_gbps_gpu, 1),
