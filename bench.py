@@ -134,7 +134,10 @@ def stage(name):
     """Workers of an N > 1 run tell the launching parent how far they got (one short line per stage, flushed)."""
     if _WATCHDOG is not None:
         _WATCHDOG.stage = name
-    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+    # Only under OUR parent (launch_workers sets FP4_BENCH_STAGES): it reads the ranks' stdout through a pipe and swallows these
+    # markers.  Under the driver's own torchrun nothing but rank 0's ONE JSON line may reach stdout - there the rank-side watchdog
+    # (stderr) is what reports a stuck stage.
+    if os.environ.get("FP4_BENCH_STAGES") == "1" and int(os.environ.get("WORLD_SIZE", "1")) > 1:
         print(f"{STAGE_TAG} rank={os.environ.get('RANK', '0')} stage={name}", flush=True)
 
 
@@ -201,6 +204,7 @@ def launch_workers(n, argv, script=None, timeout_s=None, out=None, deadline_s=48
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env["FP4_BENCH_DEADLINE_S"] = str(deadline_s)
+    env["FP4_BENCH_STAGES"] = "1"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), script or os.path.abspath(__file__), *argv]
     out = out or sys.stdout

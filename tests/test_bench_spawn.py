@@ -107,3 +107,24 @@ def test_the_rank_side_watchdog_prints_the_finished_headline_and_leaves(tmp_path
     rec = json.loads(p.stdout.strip().splitlines()[-1])
     assert rec["value"] == 1.0 and "timed-region-done" in rec["incomplete"]
     assert "deadline of 2 s passed in stage 'timed-region-done'" in p.stderr
+
+
+def test_stage_markers_never_reach_stdout_without_our_parent(tmp_path):
+    """The driver starts N > 1 under its own torchrun and expects ONE JSON line on stdout: the progress markers are only written
+    when launch_workers (which swallows them) asked for them."""
+    import subprocess
+
+    worker = _script(tmp_path, f"""
+        import sys
+        sys.path.insert(0, {REPO!r})
+        import bench
+        bench.stage("started")
+        bench.stage("done")
+        print("only line")
+    """)
+    env = dict(os.environ, WORLD_SIZE="2", RANK="1")
+    env.pop("FP4_BENCH_STAGES", None)
+    p = subprocess.run([sys.executable, worker], capture_output=True, text=True, timeout=100, env=env)
+    assert p.returncode == 0 and p.stdout.strip() == "only line"
+    p = subprocess.run([sys.executable, worker], capture_output=True, text=True, timeout=100, env=dict(env, FP4_BENCH_STAGES="1"))
+    assert "@@fp4-bench rank=1 stage=started" in p.stdout
