@@ -3,10 +3,26 @@
 # batch-1 GEMV up at the long / tall decode shapes?  Three builds of csrc/gemv_fp4.hip (baseline, -DFP4_EXP_BITOP3, -DFP4_EXP_RELAID)
 # linked with tools/exp_gemv.hip (cross-compiled beforehand into build_tmp/exp/, see profiles/r03_gemv_relayout_attempt.txt), timed
 # HBM-cold and cache-hot through the C ABI, then SQ counters of each build at 4096 x 14336.   Usage: tools/exp_relayout.sh OUTDIR
+#
+# Build first (works without a GPU; the binaries travel to the GPU box with the snapshot):  tools/exp_relayout.sh --build
 set -e
+cd "$(dirname "$0")/.."
+if [ "$1" = "--build" ]; then
+    python3 torch-bnb-fp4_amd/build.py --no-ext > /dev/null   # the other translation units' objects (build_tmp/obj) are linked as they are
+    mkdir -p build_tmp/exp
+    objs=$(ls build_tmp/obj/*.o | grep -v gemv_fp4)
+    for v in base: bitop3:-DFP4_EXP_BITOP3 relaid:-DFP4_EXP_RELAID; do
+        name=${v%%:*}; flag=${v#*:}
+        /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -mllvm -amdgpu-kernarg-preload-count=16 $flag \
+            -Iinclude -Itorch-bnb-fp4_amd/csrc -c torch-bnb-fp4_amd/csrc/gemv_fp4.hip -o build_tmp/exp/gemv_$name.o
+        /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off $flag -Iinclude -Itorch-bnb-fp4_amd/csrc \
+            -c tools/exp_gemv.hip -o build_tmp/exp/tool_$name.o
+        /opt/rocm/bin/hipcc --offload-arch=gfx950 build_tmp/exp/tool_$name.o build_tmp/exp/gemv_$name.o $objs -o build_tmp/exp/exp_gemv_$name
+    done
+    exit 0
+fi
 out=${1:-gpurun_out/r3_relayout}
 mkdir -p "$out"
-cd "$(dirname "$0")/.."
 for shape in "4096 4096" "28672 4096" "4096 14336"; do
     for b in base bitop3 relaid; do
         echo "### $b  $shape" | tee -a "$out/timing.txt"
