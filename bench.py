@@ -521,7 +521,9 @@ def main():
 
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         # a rendezvous / RCCL initialisation that does not complete raises here with its reason (well inside the parent's deadline)
-        init_timeout = datetime.timedelta(seconds=max(30.0, min(180.0, float(os.environ.get("FP4_BENCH_DEADLINE_S", "480")) / 3)))
+        # (the same timeout then governs every collective of the group: it must cover the rank-0-only extras the other ranks sit
+        #  out in the final barrier - about half a minute - so it is a large share of the deadline, not a few seconds)
+        init_timeout = datetime.timedelta(seconds=max(60.0, min(300.0, float(os.environ.get("FP4_BENCH_DEADLINE_S", str(args.deadline))) * 0.6)))
         try:
             if backend == "nccl":
                 dist.init_process_group("nccl", device_id=dev, timeout=init_timeout)
