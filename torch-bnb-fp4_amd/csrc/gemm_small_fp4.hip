@@ -185,6 +185,8 @@ __global__ __launch_bounds__(512) void gemm16_mfma_kernel(const uint16_t *__rest
                                                           int B, int M, int K, int mode) {
     // ROWT 16-row tiles per workgroup share one B fragment (x slice): x is re-read by every workgroup, so taller
     // workgroups cut that L2 traffic (B*K*2 bytes each) at the price of fewer workgroups
+    // (STAGE = false - direct 8-byte fragment loads - lost every sweep and is no longer instantiated since round 3; the branch stays as
+    //  the record of the alternative.)
     // STAGE: the A-fragment layout wants 8 bytes per lane from 16 different rows (32-byte segments per row per
     // instruction); instead each wave pulls its 16 x (32*NBW)-byte region with row-contiguous 16-byte loads and
     // re-reads it from a wave-private LDS image (no workgroup barrier).  Each image row is followed by that row's NBW

@@ -438,7 +438,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemv32_kernel(const float *__restr
 // ---- f32 activations, register-x geometry (same structure as gemv16_regx_kernel) -------------------------------
 // x slice as 32 floats per chunk in VGPRs; weights decoded through the bit-faithful CODE_PARAM f32 table in LDS
 // (16 consecutive dwords: every read is a conflict-free broadcast); (sum x*code) * absmax per chunk, f32 throughout.
-template <int KSPLIT, int G, int ITERS, bool PERM>
+// (A table-free variant - fp16 pairs of 12*code widened by v_fma_mix - was 10 % faster but outside parity bar 2 at f32; removed in round 3.)
+template <int KSPLIT, int G, int ITERS>
 __global__ __launch_bounds__(256) void gemv32_regx_kernel(const float *__restrict__ x, const uint8_t *__restrict__ W,
                                                           const float *__restrict__ absmax, const float *__restrict__ bias,
                                                           const float *residual, float *out, int M, int K, int bs_shift) {
@@ -494,35 +495,15 @@ __global__ __launch_bounds__(256) void gemv32_regx_kernel(const float *__restric
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             float s0 = 0.0f, s1 = 0.0f;
-            if constexpr (PERM) {
-                // table-free decode (see decode8): fp16 pairs of 12*code, widened by v_fma_mix against the f32 x
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    uint32_t P[4];
-                    decode8<FP4_DTYPE_F16>(wq[it][g][j], P);
-                    const f32x4 xa = xv[g][2 * j], xb = xv[g][2 * j + 1];  // x0..x3, x4..x7 of this dword
-                    const f16x2 p0 = __builtin_bit_cast(f16x2, P[0]), p1 = __builtin_bit_cast(f16x2, P[1]);
-                    const f16x2 p2 = __builtin_bit_cast(f16x2, P[2]), p3 = __builtin_bit_cast(f16x2, P[3]);
-                    s0 = __builtin_fmaf(float(p0.x), xa.x, s0);  // e0
-                    s1 = __builtin_fmaf(float(p2.x), xa.y, s1);  // e1
-                    s0 = __builtin_fmaf(float(p0.y), xa.z, s0);  // e2
-                    s1 = __builtin_fmaf(float(p2.y), xa.w, s1);  // e3
-                    s0 = __builtin_fmaf(float(p1.x), xb.x, s0);  // e4
-                    s1 = __builtin_fmaf(float(p3.x), xb.y, s1);  // e5
-                    s0 = __builtin_fmaf(float(p1.y), xb.z, s0);  // e6
-                    s1 = __builtin_fmaf(float(p3.y), xb.w, s1);  // e7
-                }
-            } else {
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {  // weights 4q..4q+3 of the chunk = bytes 2q, 2q+1
-                    const uint32_t h = (wq[it][g][q >> 1] >> (16 * (q & 1))) & 0xFFFFu;
-                    s0 = __builtin_fmaf(s_lut[(h >> 4) & 15u], xv[g][q].x, s0);
-                    s1 = __builtin_fmaf(s_lut[h & 15u], xv[g][q].y, s1);
-                    s0 = __builtin_fmaf(s_lut[(h >> 12) & 15u], xv[g][q].z, s0);
-                    s1 = __builtin_fmaf(s_lut[(h >> 8) & 15u], xv[g][q].w, s1);
-                }
+            for (int q = 0; q < 8; ++q) {  // weights 4q..4q+3 of the chunk = bytes 2q, 2q+1
+                const uint32_t h = (wq[it][g][q >> 1] >> (16 * (q & 1))) & 0xFFFFu;
+                s0 = __builtin_fmaf(s_lut[(h >> 4) & 15u], xv[g][q].x, s0);
+                s1 = __builtin_fmaf(s_lut[h & 15u], xv[g][q].y, s1);
+                s0 = __builtin_fmaf(s_lut[(h >> 12) & 15u], xv[g][q].z, s0);
+                s1 = __builtin_fmaf(s_lut[(h >> 8) & 15u], xv[g][q].w, s1);
             }
-            p = __builtin_fmaf(s0 + s1, am[it][g] * (PERM ? (1.0f / 12.0f) : 1.0f), p);
+            p = __builtin_fmaf(s0 + s1, am[it][g], p);
         }
         p = dpp_add<0x128>(p);
         p = dpp_add<0x124>(p);
@@ -554,12 +535,12 @@ __global__ __launch_bounds__(256) void gemv32_regx_kernel(const float *__restric
     }
 }
 
-template <int KSPLIT, int G, int ITERS, bool PERM>
+template <int KSPLIT, int G, int ITERS>
 int launch32_regx(const void *x, const uint8_t *W, const float *absmax, const void *bias, const void *residual, void *out, int M,
                   int K, int bs_shift, hipStream_t stream) {
     constexpr int rows_per_block = 2 * (4 / KSPLIT) * ITERS;
     const unsigned blocks = (unsigned)((M + rows_per_block - 1) / rows_per_block);
-    hipLaunchKernelGGL((gemv32_regx_kernel<KSPLIT, G, ITERS, PERM>), dim3(blocks), dim3(256), 0, stream,
+    hipLaunchKernelGGL((gemv32_regx_kernel<KSPLIT, G, ITERS>), dim3(blocks), dim3(256), 0, stream,
                        reinterpret_cast<const float *>(x), W, absmax, reinterpret_cast<const float *>(bias),
                        reinterpret_cast<const float *>(residual), reinterpret_cast<float *>(out), M, K, bs_shift);
     return FP4_OK;
@@ -580,9 +561,9 @@ int dispatch32_regx(int iters, const void *x, const uint8_t *W, const float *abs
     }
 #define FP4_R32(KS, GG)                                                                                                   \
     switch (iters) {                                                                                                      \
-        case 1: return launch32_regx<KS, GG, 1, false>(x, W, absmax, bias, residual, out, M, K, bs_shift, stream);        \
-        case 2: return launch32_regx<KS, GG, 2, false>(x, W, absmax, bias, residual, out, M, K, bs_shift, stream);        \
-        default: return launch32_regx<KS, GG, 4, false>(x, W, absmax, bias, residual, out, M, K, bs_shift, stream);       \
+        case 1: return launch32_regx<KS, GG, 1>(x, W, absmax, bias, residual, out, M, K, bs_shift, stream);        \
+        case 2: return launch32_regx<KS, GG, 2>(x, W, absmax, bias, residual, out, M, K, bs_shift, stream);        \
+        default: return launch32_regx<KS, GG, 4>(x, W, absmax, bias, residual, out, M, K, bs_shift, stream);       \
     }
     if (C <= 32) { FP4_R32(1, 1) }
     if (C <= 64) { FP4_R32(2, 1) }
