@@ -14,6 +14,9 @@
 #include <vector>
 
 #include "torch_bnb_fp4_hip.h"
+#ifdef FP4_EXP_STAMPS
+extern "C" int fp4_exp_set_stamps(void *);  // csrc/gemv_fp4.hip, diagnostic build only
+#endif
 
 #define CK(x)                                                                             \
     do {                                                                                  \
@@ -191,6 +194,53 @@ int main(int argc, char **argv) {
         {"default heuristic", -1},
     };
     if (quick) variants = {{"default heuristic", -1}};
+#ifdef FP4_EXP_STAMPS
+    {   // per-wave timeline of ONE HBM-cold launch of the default geometry (the last of a graph of R back-to-back launches)
+        const size_t kMaxWaves = 1 << 17;
+        unsigned long long *dstamps;
+        CK(hipMalloc(&dstamps, kMaxWaves * 4 * 8));
+        CK(hipMemset(dstamps, 0, kMaxWaves * 4 * 8));
+        fp4_exp_set_stamps(dstamps);
+        fp4_hip_set_variant("gemv", -1);
+        for (int rep = 0; rep < 3; ++rep) {
+            T.run("stamped gemv default cold", R, bytes, [&] {
+                for (int i = 0; i < R; ++i) fp4_hip_gemv(x, packed[i % R], absmax[i % R], nullptr, y, M, K, 64, FP4_DTYPE_BF16, T.s);
+            });
+        }
+        std::vector<unsigned long long> hs(kMaxWaves * 4);
+        CK(hipMemcpy(hs.data(), dstamps, hs.size() * 8, hipMemcpyDeviceToHost));
+        std::vector<double> t[4];
+        unsigned long long base = ~0ull;
+        size_t nw = 0;
+        for (size_t w = 0; w < kMaxWaves; ++w)
+            if (hs[4 * w]) base = std::min(base, hs[4 * w]), nw = w + 1;
+        for (size_t w = 0; w < nw; ++w)
+            if (hs[4 * w])
+                for (int i = 0; i < 4; ++i) t[i].push_back((hs[4 * w + i] - base) * 0.01);  // 100 MHz ticks -> us
+        const char *names[4] = {"entry", "loads issued", "last data consumed", "exit"};
+        printf("per-wave stamps of one cold launch, us after the first wave's entry (%zu waves)\n", t[0].size());
+        for (int i = 0; i < 4; ++i) {
+            std::sort(t[i].begin(), t[i].end());
+            auto q = [&](double f) { return t[i][std::min(t[i].size() - 1, size_t(f * t[i].size()))]; };
+            printf("  %-20s min %6.2f  p10 %6.2f  p50 %6.2f  p90 %6.2f  p99 %6.2f  max %6.2f\n", names[i], q(0.0), q(0.10), q(0.50), q(0.90), q(0.99),
+                   t[i].back());
+        }
+        // lifetime of a wave and its waiting share
+        std::vector<double> life, wait;
+        for (size_t w = 0; w < nw; ++w)
+            if (hs[4 * w]) {
+                life.push_back((hs[4 * w + 3] - hs[4 * w]) * 0.01);
+                wait.push_back((hs[4 * w + 2] - hs[4 * w + 1]) * 0.01);
+            }
+        std::sort(life.begin(), life.end());
+        std::sort(wait.begin(), wait.end());
+        printf("  wave lifetime        p10 %6.2f  p50 %6.2f  p90 %6.2f   loads issued -> last data consumed  p10 %6.2f  p50 %6.2f  p90 %6.2f\n",
+               life[life.size() / 10], life[life.size() / 2], life[life.size() * 9 / 10], wait[wait.size() / 10], wait[wait.size() / 2],
+               wait[wait.size() * 9 / 10]);
+        fp4_exp_set_stamps(nullptr);
+        fflush(stdout);
+    }
+#endif
     for (auto &v : variants) {
         if (fp4_hip_set_variant("gemv", v.second)) {
             printf("set_variant failed\n");

@@ -32,6 +32,25 @@
 
 #include "gemv_common.h"
 
+#ifdef FP4_EXP_STAMPS
+// Diagnostic build only (tools/exp_gemv.hip -DFP4_EXP_STAMPS): per-wave wall-clock stamps (s_memrealtime, 100 MHz) of the register-x
+// kernel - entry, loads issued, last data consumed, exit - written to a buffer of their own; no output value depends on them.
+__device__ unsigned long long *fp4_exp_stamps = nullptr;
+extern "C" int fp4_exp_set_stamps(void *buf) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(fp4_exp_stamps), &buf, sizeof(buf));
+}
+#define FP4_STAMP(i)                                                                                        \
+    do {                                                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+        const unsigned long long t_ = __builtin_amdgcn_s_memrealtime();                                     \
+        if ((threadIdx.x & 63) == 0 && fp4_exp_stamps)                                                      \
+            fp4_exp_stamps[(size_t(blockIdx.x) * WAVES + (threadIdx.x >> 6)) * 4 + (i)] = t_;               \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+    } while (0)
+#else
+#define FP4_STAMP(i)
+#endif
+
 namespace fp4 {
 
 namespace {
@@ -186,6 +205,7 @@ __global__ __launch_bounds__(WAVES * 64, (G >= 4 ? 4 : 1)) void gemv16_regx_kern
     constexpr int RG = WAVES / KSPLIT;           // row-pair groups per workgroup
     constexpr int kRowsPerBlock = 2 * RG * ITERS;
     __shared__ float s_part[kRowsPerBlock][KSPLIT];
+    FP4_STAMP(0);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -263,6 +283,7 @@ __global__ __launch_bounds__(WAVES * 64, (G >= 4 ? 4 : 1)) void gemv16_regx_kern
             for (int g = 0; g < G; ++g) load_w(it, g);
         }
     }
+    FP4_STAMP(1);
     // permute x to decode8's pairing: (x0,x2) (x4,x6) (x1,x3) (x5,x7) per group of 8
     u32x4 xd[G][4];
     auto permute_x = [&](int g) {
@@ -326,6 +347,7 @@ __global__ __launch_bounds__(WAVES * 64, (G >= 4 ? 4 : 1)) void gemv16_regx_kern
             for (int g = 0; g < G; ++g) consume(it, g);
         }
     }
+    FP4_STAMP(2);
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
         float p = pacc[it];
@@ -366,6 +388,7 @@ __global__ __launch_bounds__(WAVES * 64, (G >= 4 ? 4 : 1)) void gemv16_regx_kern
             if (row < M) store_row<DT>(out, bias, residual, row, t * (1.0f / 12.0f), mode);
         }
     }
+    FP4_STAMP(3);
 }
 
 // ---- f32 activations: CODE_PARAM f32 table in LDS -----------------------------------------------
