@@ -246,7 +246,7 @@ def test_partial_f32_output_and_k_split_sum(dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("kernel", [-1, 0, 1 | (1 << 4), 1 | (2 << 4), 1 | (1 << 4) | (2 << 14)])  # default; VALU kernel; matrix-core kernel: 1 / 2 row tiles, 8 blocks per pass wherever they divide K
+@pytest.mark.parametrize("kernel", [-1, 0, 1 | (1 << 4), 1 | (2 << 4), 1 | (2 << 10)])  # default; VALU kernel; matrix-core kernel: 1 / 2 row tiles; the persistent form wherever it applies (K = 4096)
 @pytest.mark.parametrize("B", [1, 2, 4, 5, 8, 9, 13, 16])
 @pytest.mark.parametrize("M,K", [(4096, 4096), (1024, 4096), (2048, 768), (66, 2048), (257, 1024), (300, 8192), (40, 14336), (33, 512),
                                  (130, 11008), (48, 1472), (70, 5120), (36, 13824)])
@@ -277,8 +277,8 @@ def test_small_batch_persistent_kernel(dtype, B, M):
     """The persistent matrix-core kernel (K = 4096; x image for <= 4 / <= 8 rows, register-resident B fragments above; by
     default only on tall weights) forced at every size:
     fewer tiles than workgroups, exactly one tile each, ragged last tile, and several tiles per workgroup (M = 20000:
-    1250 tiles over 512 / 256 workgroups, i.e. the prefetch-next-tile loop).  Same bar as every other small-batch kernel, and
-    bit-identical to the one-shot kernel (same tile arithmetic, same summation order)."""
+    1250 tiles over 512 / 256 workgroups, i.e. the prefetch-next-tile loop).  Same bar as every other small-batch kernel, next to
+    the one-shot kernel on the same operands."""
     K = 4096
     c = case(M, K, seed=shape_seed(M, K))
     x_t, b_t, exact, scale = c.rows(B, B + M, dtype)
@@ -290,8 +290,11 @@ def test_small_batch_persistent_kernel(dtype, B, M):
         y_one_shot = hipabi.gemm_small(x_t, P, A, M, K, 64, bias=b_t)
     finally:
         hipabi.set_variant("gemm_small", -1)
-    assert torch.equal(y, y_one_shot)
+    # two different K partitions over the eight waves (one 8-block slice per wave vs two 4-block passes): both meet the bar, and they
+    # agree to within the rounding of the last f32 additions
     assert_within_bar(y, exact, scale, dtype)
+    assert_within_bar(y_one_shot, exact, scale, dtype)
+    assert float((y == y_one_shot).float().mean()) > 0.9
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])

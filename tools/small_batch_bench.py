@@ -56,7 +56,7 @@ for B in (1, 2, 3, 4, 8, 12, 16):
     x = torch.randn(B, K, device=dev).to(torch.bfloat16)
     per_kernel = {}
     for kname, kv in (("valu", 0), ("mfma rt1", 1 | (1 << 4)), ("mfma rt2", 1 | (2 << 4)), ("mfma rt1 no-xstage", 1 | (1 << 4) | (1 << 9)),
-                      ("mfma persistent", 1 | (2 << 10)), ("mfma one-shot", 1 | (1 << 10)), ("mfma 4 blocks/pass", 1 | (1 << 10) | (1 << 14)), ("mfma 8 blocks/pass", 1 | (1 << 10) | (2 << 14))):
+                      ("mfma persistent", 1 | (2 << 10)), ("mfma one-shot", 1 | (1 << 10))):
         if kv == 0 and B > 8:
             continue
         hipabi.set_variant("gemm_small", kv)

@@ -577,7 +577,6 @@ __global__ __launch_bounds__(512) void gemm16_mfma_persist_kernel(const uint16_t
 std::atomic<int> g_mfma_rowt{-1};     // force 1 or 2 row tiles per workgroup
 std::atomic<int> g_mfma_xstage{-1};   // 0 = B fragments straight from global even for batch <= 8
 std::atomic<int> g_mfma_persist{-1};  // 0 = never the persistent kernel, 1 = whenever it applies
-std::atomic<int> g_mfma_nbw4{-1};     // 1 = at most 4 blocks per wave and pass (pass-ahead loads), 0 = 8 wherever they divide K
 
 template <int DT>
 int dispatch_mfma(const void *x, const uint8_t *W, const float *absmax, const void *bias, const void *residual, void *out, int B, int M,
@@ -585,15 +584,19 @@ int dispatch_mfma(const void *x, const uint8_t *W, const float *absmax, const vo
     if (K % 512) return -1;
     const int units = K / 512;  // quant blocks per wave over the whole K
     const int v_rowt = g_mfma_rowt.load(std::memory_order_relaxed),
-              v_xstage = g_mfma_xstage.load(std::memory_order_relaxed), v_persist = g_mfma_persist.load(std::memory_order_relaxed),
-              v_nbw4 = g_mfma_nbw4.load(std::memory_order_relaxed);  // sweep hooks, one snapshot per call
+              v_xstage = g_mfma_xstage.load(std::memory_order_relaxed), v_persist = g_mfma_persist.load(std::memory_order_relaxed);  // sweep hooks, one snapshot per call
     // Measured (profiles/r01_f_small_batch_shapes.txt): two row tiles per workgroup (x fetched once per 32 rows) only pay
     // for more than 4 activation rows on tall weights; at 188 VGPRs they leave one 8-wave workgroup per CU.
     const int rowt = v_rowt > 0 ? v_rowt : ((B > 4 && M >= 32 * 256) ? 2 : 1);
     const unsigned blocks = (unsigned)((M + 16 * rowt - 1) / (16 * rowt));
     // x staged per wave in LDS: always for <= 4 rows (33 KB, two workgroups per CU still fit); for 5..8 rows (66 KB, one
     // workgroup per CU) only while the grid is a single round anyway
-    if (v_persist != 0 && v_rowt <= 0 && v_xstage != 0 && K == 4096) {
+    // Round 3 (profiles/r03_small_batch_dispatch.txt): with a single tile per workgroup the persistent form has nothing to prefetch
+    // and its 8-block single pass is behind the one-shot kernel's two 4-block passes with pass-ahead loads (4096 x 4096: 4.96 -> 4.56 us
+    // at 2..4 rows, 14336 x 4096: 12.0 -> 10.8); from 5 rows up on more than 4096 rows it is what keeps the x fragments out of the
+    // texture path (14336 x 4096 x 8 rows: 11.0 vs 13.3 us), and on very tall weights it wins at every row count.
+    const bool persist_auto = B <= 4 ? M >= 16384 : M > 4096;
+    if (v_persist != 0 && v_rowt <= 0 && v_xstage != 0 && K == 4096 && (v_persist == 1 || persist_auto)) {
         // Up to 4 rows two workgroups fit a CU (78 KB of LDS each), above that one (111 KB of LDS / 166 VGPRs).
         const int ntiles = (M + 15) / 16, resident = (B <= 4 ? 2 : 1) * device_cu_count();
         // measured (profiles/r01_f_small_batch_shapes.txt): never slower than the one-shot kernel, level with it while
@@ -646,9 +649,9 @@ int dispatch_mfma(const void *x, const uint8_t *W, const float *absmax, const vo
     } else {                    \
         FP4_MF(NBW, 1);         \
     }
-    // 8 blocks per wave and pass only where that is the whole K (one pass); with several passes 4 blocks + the pass-ahead loads
-    // win (8192 x 8192 x 4 rows: 12.4 -> 10.6 us, 28672 x 8192: 36 -> 33 us; profiles/r01_f_small_batch_pass_ahead.txt)
-    if (units % 8 == 0 && (v_nbw4 == 0 || (v_nbw4 < 0 && units == 8))) { FP4_MF_RT(8) }
+    // At most 4 blocks per wave and pass, the next pass's loads in flight (8192 x 8192 x 4 rows: 12.4 -> 10.6 us, 28672 x 8192: 36 -> 33 us,
+    // profiles/r01_f_small_batch_pass_ahead.txt).  Round 3: also where 8 blocks would be the whole K in one pass (K = 4096: 5.0 -> 4.6 us
+    // at 4096 rows) - the 8-block instantiations (up to 208 VGPRs) are no longer built.
     if (units % 4 == 0) { FP4_MF_RT(4) }
     if (units % 2 == 0) { FP4_MF_RT(2) }
     FP4_MF_RT(1)
@@ -707,7 +710,6 @@ void set_small_variant(int v) {
     g_mfma_rowt = rowt == 0 ? -1 : rowt;
     g_mfma_xstage = v < 0 ? -1 : ((v >> 9) & 1 ? 0 : 1);  // bit 9: B fragments straight from global
     g_mfma_persist = v < 0 ? -1 : ((v >> 10) & 3) == 1 ? 0 : (((v >> 10) & 3) == 2 ? 1 : -1);  // bits 10-11: 1 = off, 2 = force
-    g_mfma_nbw4 = v < 0 ? -1 : ((v >> 14) & 3) == 1 ? 1 : (((v >> 14) & 3) == 2 ? 0 : -1);  // bits 14-15: 1 = 4 blocks per pass, 2 = 8
 }
 
 }  // namespace fp4
@@ -769,12 +771,17 @@ int gemm_small_entry(const void *x, const uint8_t *packed, const float *absmax, 
     // matrix-core kernel: blocksize 64, K % 512 == 0; wins from 2 rows up (4.96 vs 5.11 us at 2, 5.0 vs 11.3 us at 8), mandatory above 8
     const bool mfma_ok = ok && blocksize == 64 && (K % 512) == 0;
     const int v_small = g_small_variant.load(std::memory_order_relaxed);
-    const bool want_mfma = v_small == 1 || (v_small < 0 && B >= 2);
+    // Short weights with one or two activation rows: the VALU kernel (the GEMV's geometry, no LDS staging, no workgroup barrier per tile)
+    // is ahead of the matrix-core kernels' fixed cost (1024 x 4096: 3.2 vs 3.9-4.0 us, 2048 x 4096: 3.95 vs 4.25, 2048 x 2048: 3.15 vs
+    // 3.35); from three rows (four x slices per lane) it falls behind, and everything else, a single row included (4096 x 14336: 9.0 vs
+    // 14.8 us), is faster on the matrix cores (profiles/r03_small_batch_dispatch.txt)
+    const bool short_few = M <= 2048 && B <= 2 && K <= 4096;
+    const bool want_mfma = v_small == 1 || (v_small < 0 && !short_few);
     // Row lengths that leave the matrix-core kernel below with one or two quant blocks per wave and pass (K / 512 odd: 13824; K / 512
     // = 2 mod 4: 5120, 7168), and tall weights with long rows, are faster on the one-pass kernels of gemm_wide_fp4.hip with ONE
     // column tile (profiles/r02_wide_batch_17_to_128_rows.txt: 5120 x 13824 x 16 rows 49.2 -> 26.9 us, 13824 x 5120 21.7 -> 15.6 us,
     // 28672 x 8192 52.7 -> 38.8 us); up to 4 rows the old kernel holds where K / 512 is even.
-    if (mfma_ok && v_small < 0 && B >= 2) {
+    if (mfma_ok && v_small < 0 && !short_few) {
         const int64_t units = K / 512;
         if ((units & 1) || ((units % 4) != 0 && B >= 5) || (M >= 96 * int64_t(device_cu_count()) && K >= 8192 && B >= 5))
             rc = gemm_wide_launch(dtype, x, packed, absmax, bias, residual, out, (int)B, (int)M, (int)K, mode, true, s);
