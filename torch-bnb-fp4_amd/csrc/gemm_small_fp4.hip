@@ -574,6 +574,7 @@ __global__ __launch_bounds__(512) void gemm16_mfma_persist_kernel(const uint16_t
     }
 }
 
+std::atomic<int> g_small_wide{0};     // sweep hook: 1 = try the one-pass kernels of gemm_wide_fp4.hip first, for any row count
 std::atomic<int> g_mfma_rowt{-1};     // force 1 or 2 row tiles per workgroup
 std::atomic<int> g_mfma_xstage{-1};   // 0 = B fragments straight from global even for batch <= 8
 std::atomic<int> g_mfma_persist{-1};  // 0 = never the persistent kernel, 1 = whenever it applies
@@ -709,6 +710,7 @@ void set_small_variant(int v) {
     const int rowt = v < 0 ? 0 : ((v >> 4) & 3);  // bits 4-5: row tiles per workgroup of the matrix-core kernel (0 = auto)
     g_mfma_rowt = rowt == 0 ? -1 : rowt;
     g_mfma_xstage = v < 0 ? -1 : ((v >> 9) & 1 ? 0 : 1);  // bit 9: B fragments straight from global
+    g_small_wide = v < 0 ? 0 : ((v >> 12) & 1);            // bit 12: the one-pass (wide) kernels first
     g_mfma_persist = v < 0 ? -1 : ((v >> 10) & 3) == 1 ? 0 : (((v >> 10) & 3) == 2 ? 1 : -1);  // bits 10-11: 1 = off, 2 = force
 }
 
@@ -781,9 +783,16 @@ int gemm_small_entry(const void *x, const uint8_t *packed, const float *absmax, 
     // = 2 mod 4: 5120, 7168), and tall weights with long rows, are faster on the one-pass kernels of gemm_wide_fp4.hip with ONE
     // column tile (profiles/r02_wide_batch_17_to_128_rows.txt: 5120 x 13824 x 16 rows 49.2 -> 26.9 us, 13824 x 5120 21.7 -> 15.6 us,
     // 28672 x 8192 52.7 -> 38.8 us); up to 4 rows the old kernel holds where K / 512 is even.
-    if (mfma_ok && v_small < 0 && !short_few) {
+    if (ok && blocksize == 64 && (K % 64) == 0 && g_small_wide.load(std::memory_order_relaxed))  // sweep hook
+        rc = gemm_wide_launch(dtype, x, packed, absmax, bias, residual, out, (int)B, (int)M, (int)K, mode, true, s);
+    if (rc == -1 && mfma_ok && v_small < 0 && !short_few) {
         const int64_t units = K / 512;
-        if ((units & 1) || ((units % 4) != 0 && B >= 5) || (M >= 96 * int64_t(device_cu_count()) && K >= 8192 && B >= 5))
+        // (round 3, profiles/r03_small_batch_dispatch.txt: K / 512 = 2 mod 4 also below 5 rows on tall weights - 13824 x 5120 x 2..4 rows
+        //  17.4-18.4 -> 15.3-15.6 us, while 5120 x 5120 stays on the 16-row kernel, 9.0 vs 11.7; and 13..16 rows on a short weight with
+        //  very long rows, where every workgroup re-reads all of x - 4096 x 14336 x 16 rows 18.1 -> 16.4 us)
+        const int64_t cus = device_cu_count();
+        if ((units & 1) || ((units % 4) != 0 && (B >= 5 || M >= 48 * cus)) || (M >= 96 * cus && K >= 8192 && B >= 5) ||
+            (B >= 13 && K >= 12288 && M <= 16 * cus))
             rc = gemm_wide_launch(dtype, x, packed, absmax, bias, residual, out, (int)B, (int)M, (int)K, mode, true, s);
     }
     if (rc == -1 && mfma_ok && (want_mfma || B > 8))
