@@ -801,8 +801,12 @@ int default_variant16(int M, int K) {
     const int ksplit = C <= 32 ? 1 : (C <= 64 ? 2 : 4);
     const int rows_per_iter = 2 * (4 / ksplit);
     const int max_iters = C <= 128 ? 4 : (C <= 256 ? 4 : 2);
+    // two row pairs per group once that still leaves >= 1024 workgroups, four only from 2048 workgroups up (round 3 sweep over M at
+    // K = 4096 / 2048 / 1024, profiles/r03_gemv_rows_per_workgroup.txt: 8192..14336 x 4096 0.5-2.5 % faster at two, 32768 x 1024 5 %;
+    // from 16384 x 4096 four is ahead)
     int iters = 1;
-    while (iters * 2 <= max_iters && M / (rows_per_iter * iters * 2) >= 1024) iters *= 2;
+    if (max_iters >= 2 && M / (rows_per_iter * 2) >= 1024) iters = 2;
+    if (max_iters >= 4 && M / (rows_per_iter * 4) >= 2048) iters = 4;
     return kRegxFlag | iters;
 }
 
