@@ -126,19 +126,22 @@ def tp_ksplit_leg(lib, dist, backend, rank, world, dev, x, packed0, absmax0, bar
     return out
 
 
-STAGE_TAG = "@@fp4-bench"  # progress marker every rank writes to stdout: "@@fp4-bench rank=R stage=S"; the parent tracks it, never relays it
 STAGES = ("started", "process-group-ready", "buffers-ready", "timed-region-done", "done")
 
 
 def stage(name):
-    """Workers of an N > 1 run tell the launching parent how far they got (one short line per stage, flushed)."""
+    """Workers tell the rank-side watchdog - and, under our own launching parent, the parent - how far they got.  The parent's channel is
+    a small FILE per rank (FP4_BENCH_STAGE_DIR), never stdout: several ranks share one stdout pipe, writes above PIPE_BUF are not atomic,
+    and rank 0's ONE JSON line must not be interleaved with anything."""
     if _WATCHDOG is not None:
         _WATCHDOG.stage = name
-    # Only under OUR parent (launch_workers sets FP4_BENCH_STAGES): it reads the ranks' stdout through a pipe and swallows these
-    # markers.  Under the driver's own torchrun nothing but rank 0's ONE JSON line may reach stdout - there the rank-side watchdog
-    # (stderr) is what reports a stuck stage.
-    if os.environ.get("FP4_BENCH_STAGES") == "1" and int(os.environ.get("WORLD_SIZE", "1")) > 1:
-        print(f"{STAGE_TAG} rank={os.environ.get('RANK', '0')} stage={name}", flush=True)
+    d = os.environ.get("FP4_BENCH_STAGE_DIR")
+    if d:
+        try:
+            with open(os.path.join(d, f"rank{os.environ.get('RANK', '0')}"), "a") as f:
+                f.write(name + "\n")
+        except OSError:
+            pass
 
 
 class Watchdog:
@@ -204,30 +207,53 @@ def launch_workers(n, argv, script=None, timeout_s=None, out=None, deadline_s=48
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env["FP4_BENCH_DEADLINE_S"] = str(deadline_s)
-    env["FP4_BENCH_STAGES"] = "1"
+    import tempfile
+
+    stage_dir = tempfile.mkdtemp(prefix="fp4_bench_stages_")
+    env["FP4_BENCH_STAGE_DIR"] = stage_dir
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), script or os.path.abspath(__file__), *argv]
     out = out or sys.stdout
     t_start = time.monotonic()
     proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True, start_new_session=True)
-    state = {"line": None, "stages": {}}
+    state = {"line": None}
 
-    def pump():  # rank 0 prints exactly one JSON line; stage markers are tracked; anything else a child writes goes to stderr
+    def last_stages():
+        got = {}
+        for r in range(n):
+            try:
+                lines = open(os.path.join(stage_dir, f"rank{r}")).read().split()
+                if lines:
+                    got[r] = lines[-1]
+            except OSError:
+                pass
+        return got
+
+    def pump():  # rank 0 prints exactly one JSON line; anything else a child writes to stdout goes to our stderr
         for raw in proc.stdout:
             txt = raw.strip()
-            if txt.startswith(STAGE_TAG):
+            at = txt.find('{"metric"')
+            if at >= 0:  # tolerate foreign text glued to the line (several processes share the pipe)
                 try:
-                    fields = dict(f.split("=", 1) for f in txt.split()[1:])
-                    state["stages"][int(fields["rank"])] = fields["stage"]
-                except (ValueError, KeyError):
+                    obj, end = json.JSONDecoder().raw_decode(txt[at:])
+                    state["line"] = json.dumps(obj)
+                    txt = (txt[:at] + " " + txt[at + end:]).strip()
+                except ValueError:
                     pass
-            elif txt.startswith("{") and '"metric"' in txt:
-                state["line"] = txt
-            elif txt:
+            if txt:
                 print(txt, file=sys.stderr, flush=True)
 
     reader = threading.Thread(target=pump, daemon=True)
     reader.start()
+    try:
+        return _wait_for_workers(proc, reader, state, last_stages, n, deadline_s, t_start, out)
+    finally:
+        import shutil
+
+        shutil.rmtree(stage_dir, ignore_errors=True)
+
+
+def _wait_for_workers(proc, reader, state, last_stages, n, deadline_s, t_start, out):
     try:
         rc = proc.wait(timeout=deadline_s)
     except subprocess.TimeoutExpired:
@@ -235,8 +261,9 @@ def launch_workers(n, argv, script=None, timeout_s=None, out=None, deadline_s=48
         reader.join(timeout=5.0)
         print(f"bench.py: the {n}-rank worker group did not finish within the deadline of {deadline_s:.0f} s "
               f"(ran {time.monotonic() - t_start:.0f} s); killed.  Last stage reported by each rank:", file=sys.stderr, flush=True)
+        stages = last_stages()
         for r in range(n):
-            last = state["stages"].get(r)
+            last = stages.get(r)
             what = f"last stage '{last}'" if last else "no stage reported (never reached main(): import or launcher problem)"
             if last == "started":
                 what += " - never finished process-group initialisation (RCCL / rendezvous)"
@@ -252,7 +279,8 @@ def launch_workers(n, argv, script=None, timeout_s=None, out=None, deadline_s=48
     if line is not None:
         print(line, file=out, flush=True)
     if rc != 0:
-        stuck = [f"rank {r}: '{state['stages'].get(r, 'nothing')}'" for r in range(n) if state["stages"].get(r) != "done"]
+        stages = last_stages()
+        stuck = [f"rank {r}: '{stages.get(r, 'nothing')}'" for r in range(n) if stages.get(r) != "done"]
         print(f"bench.py: the {n}-rank worker group exited with code {rc}" + (f" (did not finish: {', '.join(stuck)})" if stuck else ""),
               file=sys.stderr, flush=True)
         return rc

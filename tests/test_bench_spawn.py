@@ -67,12 +67,13 @@ def test_a_worker_group_that_outlives_the_deadline_is_killed_with_a_reason(tmp_p
 
     import bench
 
-    sleeper = _script(tmp_path, """
+    sleeper = _script(tmp_path, f"""
         import os, sys, time
-        rank = os.environ["RANK"]
-        print(f"@@fp4-bench rank={rank} stage=started", flush=True)
-        if rank == "0":
-            print(f"@@fp4-bench rank={rank} stage=process-group-ready", flush=True)
+        sys.path.insert(0, {REPO!r})
+        import bench
+        bench.stage("started")
+        if os.environ["RANK"] == "0":
+            bench.stage("process-group-ready")
         time.sleep(600)
     """)
     out = io.StringIO()
@@ -109,9 +110,10 @@ def test_the_rank_side_watchdog_prints_the_finished_headline_and_leaves(tmp_path
     assert "deadline of 2 s passed in stage 'timed-region-done'" in p.stderr
 
 
-def test_stage_markers_never_reach_stdout_without_our_parent(tmp_path):
-    """The driver starts N > 1 under its own torchrun and expects ONE JSON line on stdout: the progress markers are only written
-    when launch_workers (which swallows them) asked for them."""
+def test_stage_reports_never_touch_stdout(tmp_path):
+    """The ranks of an N > 1 run share one stdout pipe and rank 0's line is longer than PIPE_BUF, so anything another rank prints can
+    land in the middle of it: progress goes to a file per rank (only when the launching parent asked for it), stdout carries the ONE
+    JSON line and nothing else - under the driver's own torchrun as well."""
     import subprocess
 
     worker = _script(tmp_path, f"""
@@ -123,8 +125,29 @@ def test_stage_markers_never_reach_stdout_without_our_parent(tmp_path):
         print("only line")
     """)
     env = dict(os.environ, WORLD_SIZE="2", RANK="1")
-    env.pop("FP4_BENCH_STAGES", None)
+    env.pop("FP4_BENCH_STAGE_DIR", None)
     p = subprocess.run([sys.executable, worker], capture_output=True, text=True, timeout=100, env=env)
     assert p.returncode == 0 and p.stdout.strip() == "only line"
-    p = subprocess.run([sys.executable, worker], capture_output=True, text=True, timeout=100, env=dict(env, FP4_BENCH_STAGES="1"))
-    assert "@@fp4-bench rank=1 stage=started" in p.stdout
+    d = tmp_path / "stages"
+    d.mkdir()
+    p = subprocess.run([sys.executable, worker], capture_output=True, text=True, timeout=100, env=dict(env, FP4_BENCH_STAGE_DIR=str(d)))
+    assert p.stdout.strip() == "only line" and (d / "rank1").read_text().split() == ["started", "done"]
+
+
+def test_result_line_is_recovered_when_another_process_glues_text_to_it():
+    """launch_workers extracts the JSON object even if foreign text shares its line (gloo's own prints, a rank's chatter)."""
+    import bench
+
+    class FakeProc:
+        stdout = ['[Gloo] Rank 0 is connected{"metric": "m", "value": 1.5, "nested": {"a": [1, 2]}}chatter from rank 1\n', "noise\n"]
+
+    # the pump is local to launch_workers; its parsing rule is what matters and is restated here on the same inputs
+    got = None
+    for raw in FakeProc.stdout:
+        at = raw.find('{"metric"')
+        if at >= 0:
+            obj, end = json.JSONDecoder().raw_decode(raw[at:])
+            got = obj
+    assert got == {"metric": "m", "value": 1.5, "nested": {"a": [1, 2]}}
+    src = open(os.path.join(REPO, "bench.py")).read()
+    assert "raw_decode(txt[at:])" in src  # the rule above is the one launch_workers applies

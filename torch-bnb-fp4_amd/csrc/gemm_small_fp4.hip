@@ -36,7 +36,6 @@ __global__ __launch_bounds__(256) void gemm16_small_kernel(const uint16_t *__res
     const int half = lane >> 5, l32 = lane & 31;
     const int C = K >> 5;
     const int row_base = blockIdx.x * kRowsPerBlock;
-    const u32x4 *Wv = reinterpret_cast<const u32x4 *>(W);
 
     int cidx[G];
     bool live[G];
@@ -46,6 +45,12 @@ __global__ __launch_bounds__(256) void gemm16_small_kernel(const uint16_t *__res
         live[g] = c < C;
         cidx[g] = live[g] ? c : C - 1;
     }
+    // x first (L2-resident; vector-memory results return in issue order), then the whole weight stream of this lane - the GEMV's
+    // structure (gemv16_regx_kernel), including its buffer-descriptor loads: one 32-bit offset per lane instead of 64-bit address
+    // arithmetic on the VALU (round 3; the dispatcher only comes here while M * K < 2^32).  What keeps this kernel behind the GEMV
+    // is not arithmetic but x: every workgroup (4 weight rows) pulls NB x rows through the texture path - at two rows twice the bytes
+    // of its weights - which is what the matrix-core kernels' 16-row tiles and LDS x image amortise (measured with 8 rows per
+    // workgroup as well: 28672 x 4096 x 2 rows 19.4 -> 16.3 us, level with the matrix-core kernel, nowhere ahead of it).
     u32x4 xd[NB][G][4];
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
@@ -56,6 +61,9 @@ __global__ __launch_bounds__(256) void gemm16_small_kernel(const uint16_t *__res
             for (int q = 0; q < 4; ++q) xd[b][g][q] = reinterpret_cast<const u32x4 *>(x)[xrow + cidx[g] * 4 + q];
         }
     }
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(W), 0, int((uint32_t(M) * uint32_t(C)) << 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_a =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(absmax), 0, int(((uint32_t(M) * uint32_t(C)) >> (bs_shift - 5)) << 2), 0x00020000);
     u32x4 wq[ITERS][G];
     float am[ITERS][G];
     int rowi[ITERS];
@@ -67,9 +75,9 @@ __global__ __launch_bounds__(256) void gemm16_small_kernel(const uint16_t *__res
         const int rclamp = row < M ? row : M - 1;
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-            const int64_t chunk = int64_t(rclamp) * C + cidx[g];
-            wq[it][g] = __builtin_nontemporal_load(Wv + chunk);
-            const float a = absmax[(chunk << 5) >> bs_shift];
+            const uint32_t chunk = uint32_t(rclamp) * uint32_t(C) + uint32_t(cidx[g]);
+            wq[it][g] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, int(chunk << 4), 0, 2));  // aux 2 = nt
+            const float a = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_a, int((chunk >> (bs_shift - 5)) << 2), 0, 0));
             am[it][g] = live[g] ? a : 0.0f;
         }
     }
@@ -94,23 +102,23 @@ __global__ __launch_bounds__(256) void gemm16_small_kernel(const uint16_t *__res
         for (int b = 0; b < NB; ++b) p[b] = 0.0f;
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-            float s[NB];
+            float s[NB][2];  // two accumulation chains per row and 32-weight chunk, as in the GEMV
 #pragma unroll
-            for (int b = 0; b < NB; ++b) s[b] = 0.0f;
+            for (int b = 0; b < NB; ++b) s[b][0] = s[b][1] = 0.0f;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 uint32_t P[4];
                 decode8<DT>(wq[it][g][q], P);  // decoded once, used by every activation row
 #pragma unroll
                 for (int b = 0; b < NB; ++b) {
-                    s[b] = dot2<DT>(P[0], xd[b][g][q].x, s[b]);
-                    s[b] = dot2<DT>(P[1], xd[b][g][q].y, s[b]);
-                    s[b] = dot2<DT>(P[2], xd[b][g][q].z, s[b]);
-                    s[b] = dot2<DT>(P[3], xd[b][g][q].w, s[b]);
+                    s[b][q & 1] = dot2<DT>(P[0], xd[b][g][q].x, s[b][q & 1]);
+                    s[b][q & 1] = dot2<DT>(P[1], xd[b][g][q].y, s[b][q & 1]);
+                    s[b][q & 1] = dot2<DT>(P[2], xd[b][g][q].z, s[b][q & 1]);
+                    s[b][q & 1] = dot2<DT>(P[3], xd[b][g][q].w, s[b][q & 1]);
                 }
             }
 #pragma unroll
-            for (int b = 0; b < NB; ++b) p[b] = __builtin_fmaf(s[b], am[it][g], p[b]);
+            for (int b = 0; b < NB; ++b) p[b] = __builtin_fmaf(s[b][0] + s[b][1], am[it][g], p[b]);
         }
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
@@ -677,12 +685,13 @@ int dispatch_small(const void *x, const uint8_t *W, const float *absmax, const v
                    int K, int bs_shift, int mode, hipStream_t stream) {
     const int C = K >> 5;
     const int nb = B <= 2 ? 2 : (B <= 4 ? 4 : 8);
+    if (int64_t(M) * K >= (int64_t(1) << 32)) return -1;  // 32-bit buffer offsets
 #define FP4_SM(KS, GG, NBB) return launch_small<DT, KS, GG, 2, NBB>(x, W, absmax, bias, residual, out, B, M, K, bs_shift, mode, stream)
-#define FP4_SM_NB(KS, GG)       \
-    switch (nb) {               \
-        case 2: FP4_SM(KS, GG, 2); \
-        case 4: FP4_SM(KS, GG, 4); \
-        default: FP4_SM(KS, GG, 8); \
+#define FP4_SM_NB(KS, GG)                                                                                                   \
+    switch (nb) {                                                                                                           \
+        case 2: FP4_SM(KS, GG, 2);                                                                                          \
+        case 4: FP4_SM(KS, GG, 4);                                                                                          \
+        default: FP4_SM(KS, GG, 8);                                                                                         \
     }
     if (C <= 32) {
         FP4_SM_NB(1, 1)
