@@ -17,7 +17,7 @@ import torch
 
 import hipabi
 from gpu_util import NPDT, bits, case, dev, to_dev, torch_values
-from oracle import c_oracle, fp4_oracle as o
+from oracle import fp4_oracle as o
 
 pytestmark = pytest.mark.gpu
 DT16 = [torch.bfloat16, torch.float16]

@@ -80,7 +80,6 @@ def _worker(rank, world, port, q):
             # dequant in front of every third call, on alternating ranks); every result is folded into a checksum that must agree
             # across the ranks bit for bit, and every 25th call is checked against the torch.distributed path
             from torch_bnb_fp4 import dequantize_fp4
-            import torch_bnb_fp4 as pkg
             big_p = torch.randint(0, 256, (4096 * 4096 // 2, 1), dtype=torch.uint8, device=dev)
             big_a = torch.rand(4096 * 4096 // 64, device=dev)
             acc = torch.zeros(M, dtype=torch.float64, device=dev)

@@ -52,7 +52,7 @@ for M, K in shapes:
         if B <= 128:
             t_small = timeit(capture(lambda: [hipabi.gemm_small(x, packed[i], absmax[i], M, K, 64) for i in range(R)]), R)
         if 16 < B <= 64 and "--cfgs" in sys.argv:
-            for cfg in (0, 1, 2, 3):
+            for cfg in (0, 1, 2, 3, 4):
                 hipabi.set_variant("gemm_wide", cfg)
                 t_cfg[cfg] = timeit(capture(lambda: [hipabi.gemm_small(x, packed[i], absmax[i], M, K, 64) for i in range(R)]), R)
             hipabi.set_variant("gemm_wide", -1)
@@ -69,6 +69,6 @@ for M, K in shapes:
             t_ws = timeit(capture(lambda: [hipabi.gemm_small_ws(x, packed[i], absmax[i], M, K, 64, workspace=ws) for i in range(R)]), R)
         s = f"{t_small:7.2f} us" if t_small is not None else "      - "
         print(f"   rows {B:3d}: gemm_small {s}   dequant + hipBLASLt {t_ref:7.2f} us" + (f"   ratio {t_ref / t_small:4.2f}x" if t_small else "") + (f"   with workspace {t_ws:7.2f} us" if t_ws else "")
-              + ("   [16-row launches / one pass with 16 / 32 / 64 rows per workgroup: " + " ".join(f"{t_cfg[c]:.2f}" for c in sorted(t_cfg)) + "]" if t_cfg else ""), flush=True)
+              + ("   [16-row launches / one pass with 16 / 32 / 64 / 128 rows per workgroup: " + " ".join(f"{t_cfg[c]:.2f}" for c in sorted(t_cfg)) + "]" if t_cfg else ""), flush=True)
     del packed, absmax, wbuf
     torch.cuda.empty_cache()

@@ -27,7 +27,7 @@ import torch
 
 from ._ext import ext
 from .dtypes import ScalarType
-from .functional import dequantize_fp4_codebook_invoke_qtype, dequantize_fp4_qtype, gemm_4bit_inference_qtype
+from .functional import dequantize_fp4_codebook_invoke_qtype, dequantize_fp4_qtype
 
 
 class QuantData:

@@ -17,7 +17,7 @@ Nested (double-quantised) absmax is rejected, as in the reference (README.md:223
 from __future__ import annotations
 
 import json
-from typing import Dict, Mapping, Optional
+from typing import Dict, Mapping
 
 import torch
 
