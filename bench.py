@@ -309,8 +309,14 @@ def c5_leg(dist, backend, rank, world, dev, barrier, tokens=16):
             from torch_bnb_fp4 import parallel as par
 
             comm = par.oneshot_comm(None)
-            comm.timeout_us = 50_000
             probe = torch.arange(4096, device=dev, dtype=torch.float32) * (rank + 1) * 0.25
+            # first call with a generous bound: it carries each rank's one-time costs (code-object load, first touch of the peers'
+            # mappings), which can skew the ranks by more than the 50 ms the check proper allows
+            comm.timeout_us = 2_000_000
+            comm.reduce(probe, torch.float32)
+            torch.cuda.synchronize()
+            barrier()
+            comm.timeout_us = 50_000
             got = comm.reduce(probe, torch.float32)
             want = probe.clone()
             if backend == "nccl":
@@ -322,6 +328,7 @@ def c5_leg(dist, backend, rank, world, dev, barrier, tokens=16):
             ok = torch.tensor([int(comm.status()[2] == 0 and torch.equal(got, want))], device=dev if backend == "nccl" else "cpu")
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             out["oneshot_selfcheck"] = {"ok": bool(ok.item()), "memory_kind": comm.memory_kind}
+            comm.timeout_us = 1_000_000  # the leg itself: host jitter between the ranks' launches must not read as a missing peer
             if ok.item():
                 modes.append(("oneshot", True))
         except Exception as exc:
