@@ -42,5 +42,7 @@ def test_two_ranks_self_launched_over_gloo():
                {"FP4_BENCH_BACKEND": "gloo", "FP4_BENCH_C5_LAYERS": "2"})
     assert SCHEMA <= set(rec) and rec["n_gpus"] == 2 and rec["scaling"] == "weak"
     assert "error" not in rec["tp_ksplit"], rec["tp_ksplit"]
+    ss = rec["strong_scaling_row_split"]  # one 4096x4096 weight split by rows over the ranks (strong scaling, launch-bound)
+    assert "error" not in ss and ss["rows_per_gpu"] == 2048 and ss["dequant_us"] > 0 and ss["gemv_us"] > 0, ss
     c5 = rec["c5_llama3_8b_tp"]
     assert "error" not in c5 and c5["allreduces_per_token"] == 4 and "error" not in c5["dist"], c5
