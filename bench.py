@@ -491,6 +491,16 @@ def committed_traffic(prefix: str):
     return None, None
 
 
+def device_info(dev):
+    """What the box says it is (record the device next to the roofline it is priced against)."""
+    try:
+        p = torch.cuda.get_device_properties(dev)
+        return {"name": p.name, "arch": getattr(p, "gcnArchName", ""), "compute_units": p.multi_processor_count,
+                "hbm_gib": round(p.total_memory / 2**30, 1), "torch": torch.__version__, "hip": torch.version.hip}
+    except Exception as exc:  # never let a property lookup take the line down
+        return {"error": repr(exc)[:120]}
+
+
 def usable_cores() -> int:
     """Host cores this process may really use: affinity mask, capped by the cgroup CPU quota if there is one."""
     try:
@@ -676,7 +686,8 @@ def main():
                     "M": M, "K": K, "blocksize": BLOCKSIZE, "matrices_per_step": R, "gemv_passes_per_step": GR,
                     "parallelism": f"independent row shards x{world}, no collective",
                 },
-                "pct_hbm_peak": round(100 * dq_gbps_gpu / HBM_PEAK_GBPS, 2),
+                "device": device_info(dev),
+            "pct_hbm_peak": round(100 * dq_gbps_gpu / HBM_PEAK_GBPS, 2),
                 "dequant_us_per_matrix": round(dq_us, 3),
                 "gemv_us_per_layer": round(gv_us, 3),
                 "gemv_gbps": round(gv_gbps_gpu * world, 1),
