@@ -30,6 +30,13 @@ import subprocess
 import sys
 import time
 
+# The host driver of this pool only supports dmabuf IPC, and the HIP runtime reads this variable once, when it initialises: it has to be
+# in the environment before ANYTHING touches the GPU (RCCL's own peer mappings and the one-shot all-reduce's slot buffers both go through
+# hipIpcGetMemHandle).  Module top, before `import torch`, so that the driver's own torchrun (which does not pass through
+# launch_workers below) gets it as well.  HSA_IPC_ENV_AT_START records what the launcher had given us, for the result line.
+HSA_IPC_ENV_AT_START = os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 REPO = os.path.dirname(os.path.abspath(__file__))
 for _p in (REPO, os.path.join(REPO, "torch-bnb-fp4_amd")):
     if _p not in sys.path:
@@ -126,6 +133,57 @@ def tp_ksplit_leg(lib, dist, backend, rank, world, dev, x, packed0, absmax0, bar
     return out
 
 
+def _rank_identity(rank, local, dev):
+    """What this rank runs on, gathered from every rank into the N > 1 line: enough to tell N processes on N devices from N
+    processes sharing one (uuid where the runtime exposes it, PCI bus id and device index otherwise)."""
+    from torch_bnb_fp4 import comm
+
+    p = torch.cuda.get_device_properties(dev)
+    bus = getattr(p, "pci_bus_id", None)
+    return {"rank": rank, "local_rank": local, "pid": os.getpid(), "host": os.uname().nodename, "device_index": dev.index,
+            "device": comm._device_identity(dev), "pci_bus_id": None if bus is None else int(bus), "arch": getattr(p, "gcnArchName", ""),
+            "hsa_ipc_env_at_start": HSA_IPC_ENV_AT_START, "hsa_ipc_env": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}
+
+
+def group_proof(dist, backend, rank, world, local, dev):
+    """N > 1: evidence, from REAL collectives on the data-path backend, that `world` ranks on (how many) distinct devices took part -
+    so that a reader of the line does not have to trust `n_gpus` (an environment variable).  Tensors live on the GPU for the nccl (= RCCL)
+    backend, i.e. the all-reduces below cross xGMI when the ranks sit on different devices; gloo (the one-GPU rehearsal) stages on the host."""
+    where = dev if backend == "nccl" else "cpu"
+    one = torch.ones(1, dtype=torch.int64, device=where)
+    dist.all_reduce(one)  # every rank contributes 1
+    tag = torch.tensor([rank + 1], dtype=torch.int64, device=where)
+    dist.all_reduce(tag)  # every rank contributes rank + 1: N(N+1)/2 only if ranks 0..N-1 are each there once
+    ids = [None] * world
+    dist.all_gather_object(ids, _rank_identity(rank, local, dev))
+    # a float sum whose value depends on every contribution, checked on every rank against the closed form (a transport that
+    # delivered the right COUNT but the wrong DATA would show here)
+    probe = (torch.arange(1024, dtype=torch.float32, device=where) + 1.0) * float(rank + 1)
+    dist.all_reduce(probe)
+    want = (torch.arange(1024, dtype=torch.float32, device=where) + 1.0) * float(world * (world + 1) // 2)
+    data_ok = torch.tensor([int(torch.equal(probe, want))], dtype=torch.int64, device=where)
+    dist.all_reduce(data_ok, op=dist.ReduceOp.MIN)
+    try:
+        rccl = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception as exc:
+        rccl = f"unavailable ({type(exc).__name__})"
+    devices = sorted({i["device"] for i in ids})
+    return {
+        "backend": backend,
+        "collective_library": ("RCCL " + rccl) if backend == "nccl" else f"{backend} (host-staged rehearsal; RCCL {rccl} not used)",
+        "ranks_seen": int(one.item()),
+        "rank_checksum": int(tag.item()),
+        "rank_checksum_expected": world * (world + 1) // 2,
+        "allreduce_data_ok_on_every_rank": bool(data_ok.item()),
+        "distinct_devices": len(devices),
+        "distinct_pids": len({(i["host"], i["pid"]) for i in ids}),
+        "hosts": sorted({i["host"] for i in ids}),
+        "ranks": sorted(ids, key=lambda i: i["rank"]),
+        "ok": bool(one.item() == world and tag.item() == world * (world + 1) // 2 and data_ok.item() == 1
+                   and (backend != "nccl" or len(devices) == world)),
+    }
+
+
 STAGES = ("started", "process-group-ready", "buffers-ready", "timed-region-done", "done")
 
 
@@ -189,6 +247,47 @@ def _kill_group(proc, grace_s=5.0):
             continue
 
 
+def _die_with_parent():
+    """Runs in the torchrun child between fork and exec: the workers live in a session of their own (so that the deadline can kill
+    exactly them), which also takes them out of reach of a killpg aimed at this parent - so ask the kernel to TERM the child when
+    the parent goes, however it goes (SIGKILL included; torchrun's own TERM handler then ends its ranks)."""
+    try:
+        import signal
+
+        ctypes.CDLL(None, use_errno=True).prctl(1, int(signal.SIGTERM), 0, 0, 0)  # PR_SET_PDEATHSIG
+    except Exception:
+        pass
+
+
+def _forward_termination(proc):
+    """A TERM / HUP / INT sent to the launching parent (a driver's time limit, say) ends the worker group too, then the parent leaves
+    with 128 + signal.  Returns a callable that puts the previous handlers back.  (Handlers can only be set from the main thread;
+    elsewhere _die_with_parent is the only line of defence.)"""
+    import signal
+
+    previous = {}
+
+    def handler(signum, _frame):
+        print(f"bench.py: signal {signum} received: ending the worker group", file=sys.stderr, flush=True)
+        _kill_group(proc)
+        os._exit(128 + signum)
+
+    for sig in (signal.SIGTERM, signal.SIGHUP, signal.SIGINT):
+        try:
+            previous[sig] = signal.signal(sig, handler)
+        except ValueError:
+            break
+
+    def restore():
+        for sig, old in previous.items():
+            try:
+                signal.signal(sig, old)
+            except ValueError:
+                pass
+
+    return restore
+
+
 def launch_workers(n, argv, script=None, timeout_s=None, out=None, deadline_s=480.0):
     """`python bench.py --gpus N` without torchrun: start the N ranks as CHILD processes (never exec: a process that has
     touched the GPU must not be replaced, and this parent stays GPU-free so that it can relay), wait for them, print
@@ -215,8 +314,9 @@ def launch_workers(n, argv, script=None, timeout_s=None, out=None, deadline_s=48
            "--master-port", str(port), script or os.path.abspath(__file__), *argv]
     out = out or sys.stdout
     t_start = time.monotonic()
-    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True, start_new_session=True)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True, start_new_session=True, preexec_fn=_die_with_parent)
     state = {"line": None}
+    restore = _forward_termination(proc)
 
     def last_stages():
         got = {}
@@ -250,6 +350,7 @@ def launch_workers(n, argv, script=None, timeout_s=None, out=None, deadline_s=48
     finally:
         import shutil
 
+        restore()
         shutil.rmtree(stage_dir, ignore_errors=True)
 
 
@@ -319,6 +420,12 @@ def strong_split_leg(lib, dist, backend, rank, world, dev, x, packed, absmax, ba
     return out
 
 
+def _ipc_env():
+    """The state of the variable the peer mappings depend on: what the launcher gave this process, and what it ran with."""
+    return {"hsa_ipc_env_at_start": HSA_IPC_ENV_AT_START, "hsa_ipc_env": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"),
+            "fp4_comm_alloc": os.environ.get("FP4_COMM_ALLOC")}
+
+
 def c5_leg(dist, backend, rank, world, dev, barrier, tokens=16):
     """N > 1 only, outside the timed region: BASELINE config 5 - every FP4 Linear of a Llama-3-8B shaped decoder through
     Column/RowParallelFP4Linear (q/k/v/gate/up M-split, o/down K-split + one f32 all-reduce each), batch-1 decode."""
@@ -356,12 +463,13 @@ def c5_leg(dist, backend, rank, world, dev, barrier, tokens=16):
                 want = h.to(dev)
             ok = torch.tensor([int(comm.status()[2] == 0 and torch.equal(got, want))], device=dev if backend == "nccl" else "cpu")
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            out["oneshot_selfcheck"] = {"ok": bool(ok.item()), "memory_kind": comm.memory_kind}
+            out["oneshot_selfcheck"] = {"ok": bool(ok.item()), "memory_kind": comm.memory_kind, "status_word": int(comm.status()[2]),
+                                        "timed_out_lanes": int(comm.status()[3]), **_ipc_env()}
             comm.timeout_us = 1_000_000  # the leg itself: host jitter between the ranks' launches must not read as a missing peer
             if ok.item():
                 modes.append(("oneshot", True))
         except Exception as exc:
-            out["oneshot_selfcheck"] = {"ok": False, "error": repr(exc)[:300]}
+            out["oneshot_selfcheck"] = {"ok": False, "error": repr(exc)[:300], **_ipc_env()}
     for ar, graph in modes:
         try:
             token, h0, meta = db.build_token_fn(cfg, dev, torch.bfloat16, world, rank, allreduce=ar, lm_head=False, epilogues=True)
@@ -593,7 +701,6 @@ def main():
 
         import torch.distributed as dist
 
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         # a rendezvous / RCCL initialisation that does not complete raises here with its reason (well inside the parent's deadline)
         # (the same timeout then governs every collective of the group: it must cover the rank-0-only extras the other ranks sit
         #  out in the final barrier - about half a minute - so it is a large share of the deadline, not a few seconds)
@@ -606,6 +713,7 @@ def main():
         except Exception as exc:
             print(f"bench.py: rank {rank}: process-group initialisation ({backend}) failed: {type(exc).__name__}: {exc}", file=sys.stderr, flush=True)
             raise
+    proof = group_proof(dist, backend, rank, world, local, dev) if world > 1 else None
     stage("process-group-ready")
 
     lib = Lib()
@@ -657,7 +765,12 @@ def main():
         dq_total_s, gv_total_s = sum(dq_ms) / 1e3, sum(gv_ms) / 1e3
 
         times = torch.tensor([wall, dq_total_s, gv_total_s], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        per_rank = None
         if world > 1:
+            mine = torch.tensor([dq_total_s, gv_total_s], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            got = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(got, mine)  # every rank's own event-timed totals: stragglers show as a spread, not only as the MAX
+            per_rank = [g.tolist() for g in got]
             dist.all_reduce(times, op=dist.ReduceOp.MAX)
         wall, dq_total_s, gv_total_s = times.tolist()
         line = None
@@ -720,6 +833,17 @@ def main():
                 q = statistics.quantiles(us, n=4) if len(us) >= 4 else [us[0], us[len(us) // 2], us[-1]]
                 return {"median_us": round(q[1], 3), "iqr_us": round(q[2] - q[0], 3), "min_us": round(us[0], 3), "max_us": round(us[-1], 3)}
 
+            if world > 1:
+                # row e evidence: who took part (real collectives on the data-path backend) and how evenly the ranks ran
+                line["group"] = proof
+                dq_rates = [dq_b * dq_launches / t[0] / 1e9 for t in per_rank]
+                gv_us_r = [t[1] * 1e6 / gv_launches for t in per_rank]
+                line["per_rank"] = {
+                    "dequant_gbps": [round(v, 1) for v in dq_rates], "dequant_gbps_min": round(min(dq_rates), 1),
+                    "dequant_gbps_max": round(max(dq_rates), 1), "dequant_gbps_sum": round(sum(dq_rates), 1),
+                    "gemv_us": [round(v, 3) for v in gv_us_r], "gemv_us_min": round(min(gv_us_r), 3), "gemv_us_max": round(max(gv_us_r), 3),
+                    "note": "each rank's own HIP-event totals over the timed steps; `value` is world x the SLOWEST rank's rate",
+                }
             line["dequant_step_spread"] = spread(dq_ms, R)
             line["gemv_step_spread"] = spread(gv_ms, R * GR)
             _WATCHDOG.provisional = line

@@ -183,7 +183,9 @@ FP4_HIP_API int fp4_hip_gemv_partial(const void *x, const uint8_t *packed, const
  * needs no host involvement and is HIP-graph capturable.  All ranks must issue their calls on a communicator in the
  * same order, one stream per rank.  Polling is bounded: after `timeout_us` (<= 0: 2 s) without a peer's data a lane
  * records {epoch, peer} in the buffer's status word and writes NaN; fp4_hip_comm_status copies {epoch, busy, status,
- * lanes timed out} to the host (synchronous) so the caller can raise.
+ * lanes timed out} to the host (synchronous) so the caller can raise.  The status word is sticky (first time-out wins) until
+ * fp4_hip_comm_clear_status zeroes it and the lane count (synchronous; the epoch is kept, the call sequence continues), so that a
+ * transient time-out is reported once and later checks speak about later calls.
  */
 FP4_HIP_API int64_t fp4_hip_comm_bytes(int world, int64_t capacity);
 FP4_HIP_API int fp4_hip_comm_alloc(int64_t bytes, void **ptr, uint8_t handle_out[64], int *kind_out);
@@ -191,6 +193,7 @@ FP4_HIP_API int fp4_hip_comm_open(const uint8_t handle[64], void **ptr);
 FP4_HIP_API int fp4_hip_comm_close(void *ptr);
 FP4_HIP_API int fp4_hip_comm_free(void *ptr);
 FP4_HIP_API int fp4_hip_comm_status(const void *own_buffer, uint32_t out4[4]);
+FP4_HIP_API int fp4_hip_comm_clear_status(void *own_buffer);
 FP4_HIP_API int fp4_hip_allreduce_oneshot(const float *partial, void *const *peer_buffers, int rank, int world, int64_t M,
                               int64_t capacity, const void *bias, const void *residual, void *out, int out_dtype,
                               int64_t timeout_us, void *stream);

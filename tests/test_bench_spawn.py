@@ -16,6 +16,12 @@ def _script(tmp_path, body):
     return str(p)
 
 
+def _script_named(tmp_path, name, body):
+    p = tmp_path / name
+    p.write_text(textwrap.dedent(body))
+    return str(p)
+
+
 def test_launch_workers_relays_rank0_line_and_exit_code(tmp_path, capfd):
     import bench
 
@@ -58,6 +64,121 @@ def test_plain_invocation_with_gpus_gt_1_spawns_before_any_gpu_call():
     main = src[src.index("def main():"):]
     assert main.index("launch_workers(args.gpus") < main.index("torch.cuda.")
     assert "os.exec" not in src
+
+
+def test_ipc_mode_variable_is_set_before_anything_can_touch_the_gpu():
+    """HSA_ENABLE_IPC_MODE_LEGACY=0 is read by the HIP runtime when it initialises: in the WORKER path too (the driver's own torchrun
+    never passes through launch_workers) it has to be in os.environ before the first torch.cuda call - i.e. at module top, ahead of
+    `import torch` - in bench.py and in tools/decode_bench.py (imported by the C5 leg, runnable on its own under torchrun)."""
+    for rel in ("bench.py", os.path.join("tools", "decode_bench.py")):
+        src = open(os.path.join(REPO, rel)).read()
+        at = src.index('os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")')
+        assert at < src.index("\nimport torch"), rel
+        assert at < src.index("torch.cuda."), rel
+        assert at < src.index("def main("), rel
+        # and nowhere later does the worker path set it "just in time" (too late by then): the only other mention is the child env
+        later = [i for i in range(len(src)) if src.startswith('os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY"', i) and i != at]
+        assert later == [], (rel, later)
+    # behaviour, not only source: a fresh interpreter without the variable has it after importing bench, before torch.cuda is touched
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k != "HSA_ENABLE_IPC_MODE_LEGACY"}
+    code = ("import os, sys; sys.path.insert(0, %r); import bench; "
+            "print(os.environ['HSA_ENABLE_IPC_MODE_LEGACY'], bench.HSA_IPC_ENV_AT_START)" % REPO)
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and p.stdout.split() == ["0", "None"], (p.stdout, p.stderr[-500:])
+
+
+def test_group_proof_fields_from_real_collectives_world_2(tmp_path):
+    """The N > 1 line's `group` record (ranks_seen, rank checksum, gathered identities, distinct devices) comes from collectives on the
+    process group; here two gloo ranks on CPU with a stand-in identity (no GPU in this container), the real thing in test_gpu_bench.py."""
+    import subprocess
+
+    worker = _script(tmp_path, f"""
+        import json, os, sys
+        sys.path.insert(0, {REPO!r})
+        import torch, torch.distributed as dist
+        import bench
+        rank = int(os.environ["RANK"])
+        same = os.environ["SAME_DEVICE"] == "1"
+        bench._rank_identity = lambda r, l, d: {{"rank": r, "local_rank": l, "pid": os.getpid(), "host": "h",
+                                                "device": "gpu-0" if same else f"gpu-{{r}}"}}
+        dist.init_process_group("gloo")
+        got = bench.group_proof(dist, os.environ["AS_BACKEND"], rank, dist.get_world_size(), rank, None)
+        if rank == 0:
+            print(json.dumps(got))
+        dist.barrier()
+        dist.destroy_process_group()
+    """)
+    import socket
+
+    def run(same, as_backend):
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ, SAME_DEVICE=same, AS_BACKEND=as_backend)
+        p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                            "--master-port", str(port), worker], env=env, capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr[-2000:]
+        return json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+
+    g = run("1", "gloo")
+    assert g["ranks_seen"] == 2 and g["rank_checksum"] == 3 == g["rank_checksum_expected"] and g["allreduce_data_ok_on_every_rank"]
+    assert g["distinct_devices"] == 1 and g["distinct_pids"] == 2 and [r["rank"] for r in g["ranks"]] == [0, 1] and g["ok"]
+    assert "gloo" in g["collective_library"] and g["backend"] == "gloo"
+
+
+def test_sigterm_to_the_launching_parent_ends_the_worker_group(tmp_path):
+    """The worker group is a session of its own (so that the deadline can kill exactly it), hence out of reach of a killpg aimed at the
+    parent: a TERM to the parent (a driver's limit) must end the ranks too, and so must a KILL of the parent (PR_SET_PDEATHSIG)."""
+    import signal
+    import subprocess
+    import time
+
+    pids = tmp_path / "pids"
+    pids.mkdir()
+    sleeper = _script(tmp_path, f"""
+        import os, time
+        open(os.path.join({str(pids)!r}, os.environ["RANK"]), "w").write(str(os.getpid()))
+        time.sleep(600)
+    """)
+    parent_src = _script_named(tmp_path, "parent.py", f"""
+        import sys
+        sys.path.insert(0, {REPO!r})
+        import bench
+        sys.exit(bench.launch_workers(2, [], script={sleeper!r}, deadline_s=300))
+    """)
+
+    def alive(pid):
+        try:
+            os.kill(pid, 0)
+        except ProcessLookupError:
+            return False
+        try:  # a zombie waiting for its reaper is not "alive" for our purpose
+            return open(f"/proc/{pid}/stat").read().rsplit(")", 1)[1].split()[0] != "Z"
+        except OSError:
+            return False
+
+    for sig, want_rc in ((signal.SIGTERM, 128 + signal.SIGTERM), (signal.SIGKILL, -signal.SIGKILL)):
+        for f in pids.iterdir():
+            f.unlink()
+        parent = subprocess.Popen([sys.executable, parent_src], stderr=subprocess.PIPE, text=True)
+        t_end = time.monotonic() + 120
+        while len(list(pids.iterdir())) < 2 and time.monotonic() < t_end:
+            time.sleep(0.2)
+        time.sleep(0.3)
+        workers = [int(f.read_text()) for f in pids.iterdir()]
+        assert len(workers) == 2 and all(alive(w) for w in workers)
+        parent.send_signal(sig)
+        rc = parent.wait(timeout=60)
+        assert rc == want_rc, (sig, rc, parent.stderr.read()[-500:])
+        t_end = time.monotonic() + 40  # torchrun TERMs its ranks, then KILLs them after its grace period
+        while any(alive(w) for w in workers) and time.monotonic() < t_end:
+            time.sleep(0.2)
+        left = [w for w in workers if alive(w)]
+        for w in left:
+            os.kill(w, signal.SIGKILL)
+        assert not left, (sig, left)
 
 
 def test_a_worker_group_that_outlives_the_deadline_is_killed_with_a_reason(tmp_path, capfd):

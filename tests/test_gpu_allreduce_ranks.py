@@ -71,6 +71,17 @@ def same_bits(a: torch.Tensor, b: torch.Tensor) -> bool:
     return a.dtype == b.dtype and bool(torch.equal(a.view(iv), b.view(iv)))
 
 
+def finite_part_ok(y: torch.Tensor, want: torch.Tensor) -> bool:
+    """For a mismatching output: is every element that is NOT NaN bit-equal to the expected one?  (A bounded time-out writes NaN, never
+    a wrong finite value; anything else in a mismatch is a kernel bug, whatever the status word says.  `want` never holds a NaN.)"""
+    y, want = y.detach().cpu().contiguous(), want.detach().cpu().contiguous()
+    if y.dtype != want.dtype or y.shape != want.shape:
+        return False
+    iv = torch.int32 if y.dtype == torch.float32 else torch.int16
+    keep = ~torch.isnan(y.float())
+    return bool(torch.equal(y.view(iv)[keep], want.view(iv)[keep]))
+
+
 def test_the_check_is_order_sensitive():
     """Precondition of everything below (pure numpy): rank order and reversed order give different f32 bits."""
     for world in (3, 4, 5, 8):
@@ -224,6 +235,7 @@ def _grid_worker(proc, nproc, per, port, q):
         mine = [proc * per + i for i in range(per)]
         streams = {r: torch.cuda.Stream() for r in mine}
         bad, call = [], 0
+        finite_wrong = 0  # mismatches (over ALL of them, not the first few kept in `bad`) holding a wrong value that is not NaN
         for dtype in (torch.float32, torch.bfloat16):
             for n in SIZES:
                 call += 1
@@ -243,6 +255,7 @@ def _grid_worker(proc, nproc, per, port, q):
                 for r, y in ys:
                     if not same_bits(y, want):
                         bad.append((str(dtype), call, n, r, int(torch.isnan(y.float()).sum().item())))
+                        finite_wrong += not finite_part_ok(y, want)
         # back-to-back calls WITHOUT a host synchronisation in between: a rank may run one call ahead of a peer that still
         # reads (the double buffering by epoch parity is what makes that safe)
         n = 4096
@@ -260,6 +273,7 @@ def _grid_worker(proc, nproc, per, port, q):
             for r in mine:
                 if not same_bits(ys[(i, r)], want):
                     bad.append(("pipelined", first + i, n, r, int(torch.isnan(ys[(i, r)]).sum().item())))
+                    finite_wrong += not finite_part_ok(ys[(i, r)], want)
         calls = call + 12
         layer_bad = []
         if world == 8:
@@ -299,7 +313,8 @@ def _grid_worker(proc, nproc, per, port, q):
             ext.comm_close(ptr)
         for o_ in own:
             ext.comm_free(o_[0])
-        q.put({"proc": proc, "bad": bad[:8], "n_bad": len(bad), "layer_bad": layer_bad, "calls": calls, "status": status})
+        q.put({"proc": proc, "bad": bad[:8], "n_bad": len(bad), "finite_wrong": finite_wrong, "layer_bad": layer_bad, "calls": calls,
+               "status": status})
         if dist is not None:
             dist.barrier()
     finally:
@@ -338,11 +353,12 @@ def test_more_than_two_writers_streams_and_processes(nproc, per):
     if nproc == 1:
         # Several ranks as streams of ONE process need as many co-resident kernels as ranks; where the runtime does not grant that
         # (fewer hardware queues than streams), a rank waits behind a spinning one and the bounded time-out fires (NaN + status
-        # word, by design).  That is an environment limit, not a kernel result: skip - but only if EVERY mismatch is a whole-NaN
-        # time-out; a single wrong finite value still fails.  (The multi-process set-ups above and below do not depend on it.)
+        # word, by design).  That is an environment limit, not a kernel result: skip - but only if a rank's status word names a
+        # time-out AND, over ALL mismatching outputs, every element that is not NaN carries the expected bits; a single wrong finite
+        # value - next to NaNs or not - still fails.  (The multi-process set-ups above and below do not depend on it.)
         r = results[0]
-        timed_out = any(st[2] != 0 for st in r["status"])
-        if timed_out and all(b[-1] == b[2] or b[-1] > 0 for b in r["bad"]) and r["n_bad"] > 0:
+        timed_out = any(st[2] != 0 and st[3] > 0 for st in r["status"])
+        if timed_out and r["n_bad"] > 0 and r["finite_wrong"] == 0 and r["layer_bad"] == []:
             pytest.skip(f"{per} kernels of one process were not co-scheduled on this box (bounded time-out taken): {r['status'][0]}")
     for r in results:
         assert r["n_bad"] == 0 and r["layer_bad"] == [], r

@@ -126,6 +126,19 @@ def _worker(rank, world, port, q):
             except RuntimeError as exc:
                 res["timeout"] = str(exc)
             res["timeout_nan"] = bool(torch.isnan(y.float()).all().item())
+            res["status_after_check"] = lonely.status()
+        dist.barrier()
+        # the status is reported once, not for ever: rank 1 catches up with the call it sat out (rank 0's data for that epoch is
+        # still in its slot), then both ranks reduce again - correct sum, clean status, check() silent on both
+        if rank == 1:
+            lonely.reduce(part, torch.bfloat16)
+            torch.cuda.synchronize()
+        dist.barrier()
+        y2 = lonely.reduce(part, torch.bfloat16)
+        lonely.check()
+        assert bool((y2.float() == 2.0).all().item()), "rank %d: the call after a time-out is wrong" % rank
+        if rank == 0:
+            res["after_timeout"] = (bool((y2.float() == 2.0).all().item()), lonely.status())
         dist.barrier()
         lonely.close()
         if rank == 0:
@@ -169,3 +182,6 @@ def test_tensor_parallel_two_ranks_on_one_gpu():
     assert res["status"][2] == 0 and res["status"][3] == 0 and res["status"][1] == 0, res["status"]
     assert res["memory_kind"] in ("uncached", "fine-grained", "default")
     assert "timed out waiting for rank 1" in res["timeout"] and res["timeout_nan"], res["timeout"]
+    # check() clears what it reports (fp4_hip_comm_clear_status): epoch kept, status word and lane count back to zero
+    assert res["status_after_check"] == (1, 0, 0, 0), res["status_after_check"]
+    assert res["after_timeout"] == (True, (2, 0, 0, 0)), res["after_timeout"]

@@ -307,3 +307,47 @@ def test_fused_layer_dtype_casts_never_touch_the_scales(fake, monkeypatch):
         y = layer(x)
         want = o.linear_epilogue(o.gemv_exact(x.float().numpy().reshape(-1), p, a, M, K, 64), "bfloat16", bias.to(torch.bfloat16).float().numpy())
         assert np.array_equal(y.float().numpy().reshape(-1), want)
+
+
+def test_save_fp4_model_dtype_metadata_and_tensor_parallel_guard(monkeypatch, tmp_path):
+    """save_fp4_model: (a) a plain FusedFP4Linear records the dtype its weight was quantised from (its quant_state's), not a
+    hard-coded float16; (b) a model holding tensor-parallel wrappers (one rank's shard each) is refused with a clear message instead
+    of being written as complete-looking layers of the wrong size that load back without their collective."""
+    import json
+    import socket
+
+    import torch.distributed as dist
+    from safetensors.torch import load_file
+
+    from torch_bnb_fp4 import fused, parallel as par, serialization as ser
+
+    monkeypatch.setattr(fused, "fp4_code", lambda: torch.from_numpy(o.TREE_TABLE.copy()))
+    monkeypatch.setattr(par, "fp4_code", lambda: torch.from_numpy(o.TREE_TABLE.copy()))
+    M, K = 32, 128
+    rng = np.random.default_rng(3)
+    p, a = o.quantize_fp4((rng.standard_normal(M * K) * 0.05).astype(np.float32), 64)
+    P, A = torch.from_numpy(p).view(-1, 1), torch.from_numpy(a)
+    net = nn.Sequential(fused.FusedFP4Linear.from_packed(P, A, (M, K), 64, dtype=torch.bfloat16), fused.FusedFP4Linear.from_packed(P.clone(), A.clone(), (M, K), 64))
+    path = str(tmp_path / "m.safetensors")
+    ser.save_fp4_model(net, path)
+    state = load_file(path)
+    meta = [json.loads(bytes(state[f"{i}.weight.quant_state.bitsandbytes__fp4"].tolist()).decode()) for i in (0, 1)]
+    assert meta[0]["dtype"] == "bfloat16" and meta[1]["dtype"] == "float16" and meta[0]["shape"] == [M, K]
+    assert np.array_equal(state["0.weight"].numpy().reshape(-1), p)
+    # from_linear keeps the source layer's recorded dtype
+    import types
+
+    src = types.SimpleNamespace(quant_data=net[0].quant_data)
+    assert fused.FusedFP4Linear.from_linear(src).quant_data.quant_state.dtype == torch.bfloat16
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        for layer in (par.ColumnParallelFP4Linear(P, A, (M, K), 64), par.RowParallelFP4Linear(P, A, (M, K), 64),
+                      par.FusedColumnParallelFP4([(P, A, (M, K)), (P, A, (M, K))], 64)):
+            with pytest.raises(ValueError, match="one rank's shard"):
+                ser.save_fp4_model(nn.Sequential(nn.Linear(4, 4), layer), str(tmp_path / "tp.safetensors"))
+    finally:
+        dist.destroy_process_group()

@@ -22,6 +22,9 @@ import os
 import sys
 import time
 
+# dmabuf IPC only on this pool, and the HIP runtime reads the variable once when it initialises: before anything touches the GPU
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for _p in (REPO, os.path.join(REPO, "torch-bnb-fp4_amd")):
     if _p not in sys.path:
@@ -220,7 +223,6 @@ def main():
     torch.cuda.set_device(local_dev)
     dev = torch.device("cuda", local_dev)
     if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:

@@ -194,6 +194,18 @@ extern "C" int fp4_hip_comm_status(const void *own_buffer, uint32_t out4[4]) {
     return FP4_OK;
 }
 
+extern "C" int fp4_hip_comm_clear_status(void *own_buffer) {
+    // status word + timed-out lane count (bytes 8..16 of the header); epoch and done counter stay: the call sequence goes on.
+    // Synchronous, like fp4_hip_comm_status: to be called at a sync point, with no reduction of this rank in flight.
+    if (!own_buffer || hipDeviceSynchronize() != hipSuccess ||
+        hipMemset(static_cast<uint8_t *>(own_buffer) + 8, 0, 8) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+        (void)hipGetLastError();
+        fp4::set_error("fp4_hip_comm_clear_status: cannot reset the header");
+        return FP4_ERR_INVALID_ARGUMENT;
+    }
+    return FP4_OK;
+}
+
 extern "C" int fp4_hip_allreduce_oneshot(const float *partial, void *const *peer_buffers, int rank, int world, int64_t M,
                                          int64_t capacity, const void *bias, const void *residual, void *out, int out_dtype,
                                          int64_t timeout_us, void *stream) {

@@ -372,6 +372,8 @@ std::vector<uint32_t> comm_status(int64_t own_ptr) {
     return out;
 }
 
+void comm_clear_status(int64_t own_ptr) { check_status(fp4_hip_comm_clear_status(reinterpret_cast<void *>(own_ptr))); }
+
 // partial: f32 [.., M] on this rank's GPU; returns T [.., M] = T(sum over ranks) (+ bias) (+ residual)
 torch::Tensor allreduce_oneshot(torch::Tensor partial, std::vector<int64_t> peers, int rank, int64_t capacity, ScalarTypeEnum dtype,
                                 c10::optional<torch::Tensor> bias, c10::optional<torch::Tensor> residual, int64_t timeout_us) {
@@ -443,6 +445,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("comm_close", &comm_close, "unmap a peer's buffer");
     m.def("comm_free", &comm_free, "free the own buffer");
     m.def("comm_status", &comm_status, "(own buffer) -> [epoch, busy, status, lanes timed out]  (synchronous)");
+    m.def("comm_clear_status", &comm_clear_status, "(own buffer): zero the sticky status word and the timed-out lane count (synchronous)");
     m.def("allreduce_oneshot", &allreduce_oneshot,
           "one-shot all-reduce of f32 partials over peer-mapped slots: (partial, peers, rank, capacity, dtype, bias|None, residual|None, timeout_us)");
     m.def("quantize_fp4", &quantize_fp4, "blockwise FP4 quantiser: (W, blocksize) -> (packed, absmax)");

@@ -90,9 +90,18 @@ class OneShotAllReduce:
         torch.cuda.synchronize(self.device)
         return tuple(ext.comm_status(self._own))
 
+    def reset_status(self) -> None:
+        """Zero the sticky status word and the timed-out lane count (synchronises the device; the epoch is kept, so the ranks stay
+        in step).  Call it at a sync point with no reduction of this rank in flight."""
+        torch.cuda.synchronize(self.device)
+        ext.comm_clear_status(self._own)
+
     def check(self) -> None:
+        """Raise if a reduction of this rank timed out SINCE THE LAST CHECK: the status is cleared before raising, so one transient
+        time-out is reported once and the communicator stays usable (all ranks still have to make the same calls in the same order)."""
         epoch, _, status, lanes = self.status()
         if status:
+            self.reset_status()
             raise RuntimeError(f"OneShotAllReduce: rank {self.rank} timed out waiting for rank {(status & 0xFF) - 1} in call "
                                f"{status >> 8} ({lanes} lanes gave up; {epoch} calls completed): outputs of that call are NaN")
 

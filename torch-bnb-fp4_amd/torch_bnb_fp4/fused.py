@@ -84,8 +84,9 @@ class FusedFP4Linear(nn.Module):
     # -- constructors ------------------------------------------------------------------------------------------------
     @classmethod
     def from_packed(cls, packed, absmax, shape, blocksize: int = 64, bias: Optional[torch.Tensor] = None,
-                    epilogue: int = EPILOGUE_NONE) -> "FusedFP4Linear":
-        state = QuantState(absmax, shape, fp4_code().to(packed.device), blocksize)
+                    epilogue: int = EPILOGUE_NONE, dtype: torch.dtype = torch.float16) -> "FusedFP4Linear":
+        """``dtype``: the dtype the weight was quantised from (checkpoint metadata only; the kernels follow the activation)."""
+        state = QuantState(absmax, shape, fp4_code().to(packed.device), blocksize, dtype)
         return cls(QuantData(packed, state, state.shape, original_lin=None, bias=bias), epilogue)
 
     @classmethod
@@ -102,7 +103,7 @@ class FusedFP4Linear(nn.Module):
     def from_linear(cls, layer) -> "FusedFP4Linear":
         """From a :class:`TorchFP4Linear` (shares its packed weight)."""
         qd = layer.quant_data
-        return cls.from_packed(qd.A, qd.absmax, (qd.M, qd.N), qd.blocksize, qd.bias)
+        return cls.from_packed(qd.A, qd.absmax, (qd.M, qd.N), qd.blocksize, qd.bias, dtype=getattr(qd.quant_state, "dtype", torch.float16))
 
     @classmethod
     def gate_up(cls, gate_layer, up_layer) -> "FusedFP4Linear":

@@ -179,7 +179,24 @@ class FusedColumnParallelFP4(nn.Module):
 class RowParallelFP4Linear(nn.Module):
     """K-split: this rank owns ``in_features / world`` columns; outputs are summed across ranks in f32."""
 
-    _mm_f32_out = True  # cleared the first time torch.mm(..., out_dtype=float32) turns out not to exist in this build
+    _mm_f32_out = {}  # (dtype, device type) -> does torch.mm(a, b, out_dtype=float32) exist for these operands?  Probed once, tiny.
+
+    @classmethod
+    def _has_mm_f32_out(cls, like: torch.Tensor) -> bool:
+        """Capability probe on 16x16 operands - never inferred from a failure of the real GEMM (an out-of-memory error there is a
+        RuntimeError too, and must surface as such instead of quietly moving every later call to the slower f32 path)."""
+        key = (like.dtype, like.device.type)
+        ok = cls._mm_f32_out.get(key)
+        if ok is None:
+            try:
+                a = torch.zeros(16, 16, dtype=like.dtype, device=like.device)
+                ok = torch.mm(a, a, out_dtype=torch.float32).dtype == torch.float32
+            except torch.cuda.OutOfMemoryError:
+                raise
+            except (NotImplementedError, RuntimeError, TypeError):
+                ok = False
+            cls._mm_f32_out[key] = ok
+        return ok
 
     def __init__(self, packed, absmax, shape, blocksize: int = 64, bias: Optional[torch.Tensor] = None, group=None,
                  input_is_parallel: bool = False, allreduce: str = "dist"):
@@ -221,13 +238,11 @@ class RowParallelFP4Linear(nn.Module):
                 qd.set_compute_type(xs)
             x2 = xs.reshape(-1, ks)
             part = None
-            if x2.dtype in (torch.float16, torch.bfloat16) and RowParallelFP4Linear._mm_f32_out:
+            if x2.dtype in (torch.float16, torch.bfloat16) and self._has_mm_f32_out(x2):
                 w16 = ext.dequantize_fp4_codebook(qd.A, qd.absmax, qd.code, qd.M, qd.N, qd.blocksize, qd.numel,
                                                   ScalarType.from_torch_dtype(x2.dtype).value)
-                try:
-                    part = torch.mm(x2, w16.t(), out_dtype=torch.float32)
-                except (NotImplementedError, RuntimeError, TypeError):
-                    RowParallelFP4Linear._mm_f32_out = False
+                part = torch.mm(x2, w16.t(), out_dtype=torch.float32)  # errors here (out of memory included) are the caller's to see
+                del w16
             if part is None:
                 w32 = ext.dequantize_fp4_codebook(qd.A, qd.absmax, qd.code, qd.M, qd.N, qd.blocksize, qd.numel, ScalarType.float32.value)
                 part = torch.nn.functional.linear(x2.float(), w32)

@@ -54,13 +54,15 @@ def fp4_linear_to_bnb_state(layer: TorchFP4Linear, prefix: str = "") -> Dict[str
     return _bnb_entries(prefix, qd.A, qd.absmax, qd.code, qd.blocksize, (qd.M, qd.N), qd.quant_state.dtype, layer.bias)
 
 
-def fused_linear_to_bnb_state(layer, prefix: str = "", pair_prefixes=None, dtype=torch.float16) -> Dict[str, torch.Tensor]:
+def fused_linear_to_bnb_state(layer, prefix: str = "", pair_prefixes=None, dtype=None) -> Dict[str, torch.Tensor]:
     """A :class:`~torch_bnb_fp4.fused.FusedFP4Linear` in bitsandbytes' layout.  A plain one (residual epilogue) is one entry under
     ``prefix``; a gate|up one is DE-INTERLEAVED into the two projections it was built from and written under ``pair_prefixes``
     (the rows are a load-time permutation of the bnb bytes, not a new format) - without names for the pair it cannot be saved."""
     from .fused import EPILOGUE_SILU_MUL_PAIRS, deinterleave_rows
 
     qd = layer.quant_data
+    if dtype is None:  # the dtype the weight was quantised from, as its quant_state recorded it
+        dtype = getattr(qd.quant_state, "dtype", torch.float16)
     if layer.epilogue != EPILOGUE_SILU_MUL_PAIRS:
         return _bnb_entries(prefix, qd.A, qd.absmax, qd.code, qd.blocksize, (qd.M, qd.N), dtype, layer.bias)
     if not pair_prefixes:
@@ -114,6 +116,19 @@ def save_fp4_model(model: torch.nn.Module, path: str) -> None:
     from .fused import FusedFP4Linear
     from .surgery import FusedGatedMLP
 
+    # Tensor-parallel wrappers hold ONE RANK'S shard (row slices, re-packed column ranges, shard-wise concatenations): written as they
+    # are they would read back as complete but wrong-sized plain layers, without the collective and without forward(x, residual).
+    try:
+        from . import parallel as _par
+
+        tp_types = (_par.ColumnParallelFP4Linear, _par.RowParallelFP4Linear, _par.FusedColumnParallelFP4)
+    except Exception:  # torch.distributed not built in: no such modules can exist in the model either
+        tp_types = ()
+    for name, mod in model.named_modules():
+        if tp_types and isinstance(mod, tp_types):
+            raise ValueError(f"save_fp4_model: '{name}' is a {type(mod).__name__} holding one rank's shard of its weight; save the "
+                             "unsharded model (before the tensor-parallel layers are built) and shard again after loading")
+
     tensors: Dict[str, torch.Tensor] = {}
     fp4_prefixes = []
     gated = {}  # prefix of a FusedGatedMLP's gate_up child -> (prefix for gate, prefix for up, dtype)
@@ -129,7 +144,7 @@ def save_fp4_model(model: torch.nn.Module, path: str) -> None:
         elif isinstance(mod, FusedFP4Linear):
             fp4_prefixes.append(prefix)
             g = gated.get(prefix)
-            tensors.update(fused_linear_to_bnb_state(mod, prefix, None if g is None else g[:2], torch.float16 if g is None else g[2]))
+            tensors.update(fused_linear_to_bnb_state(mod, prefix, None if g is None else g[:2], None if g is None else g[2]))
     for key, val in model.state_dict().items():
         if not any(key.startswith(p) for p in fp4_prefixes):
             tensors[key] = val.detach().cpu().contiguous()
