@@ -552,6 +552,38 @@ def c4_leg(dev, tokens=24):
     return out
 
 
+def box_stream_leg(packed, outs):
+    """What THIS box streams, in this very run, with the dequant kernel's own access geometry and no arithmetic (tools/stream_probe.hip:
+    256-thread workgroups, 4 KiB contiguous per wave, 16-byte non-temporal accesses): write only, read only, copy, and the kernel's
+    1-read : 4-write mix, each as R launches of 32 MiB of stores (or loads) rotating over the bench's own buffers - HBM-cold, HIP-graph
+    replay, HIP events, exactly like the headline.  The spec figure (8 TB/s) stays the roofline peak; this says how far the kernel is from
+    what the silicon in front of it delivers for its traffic shape."""
+    probe = ctypes.CDLL(os.path.join(REPO, "tools", "libfp4_stream_probe.so"))
+    vp, i32, i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
+    probe.fp4_probe_stream.argtypes = [i32, vp, vp, i64, vp]
+    probe.fp4_probe_stream.restype = i32
+    probe.fp4_probe_bytes.argtypes = [i32, i64]
+    probe.fp4_probe_bytes.restype = i64
+    R = len(outs)
+    n = outs[0].numel() * outs[0].element_size()  # 32 MiB: the output of one 4096x4096 -> bf16 dequant
+    assert packed[0].numel() * 4 >= n and n % 16384 == 0
+    out = {}
+    for name, mode in (("write_only", 0), ("read_only", 1), ("copy", 2), ("dequant_mix_1r_4w", 3)):
+        def run(mode=mode):
+            s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+            for i in range(R):
+                src = packed[i] if mode == 3 else outs[(i + R // 2) % R]
+                rc = probe.fp4_probe_stream(mode, src.data_ptr(), outs[i].data_ptr(), n, s)
+                if rc != 0:
+                    raise RuntimeError(f"fp4_probe_stream(mode {mode}) failed with code {rc}")
+
+        rp = capture(run)
+        time_replays(rp, 3, R)
+        us = time_replays(rp, 7, R)[0]
+        out[name] = round(probe.fp4_probe_bytes(mode, n) / us / 1e3, 1)
+    return out
+
+
 def capture(fn):
     """Capture fn() into a HIP graph (after one eager run) and return a replay callable."""
     fn()
@@ -948,6 +980,11 @@ def main():
             us = time_replays(cp, 5, 1)[0]
             extra["device_copy_gbps"] = round(2 * src.numel() / us / 1e3, 1)
             del src, dst
+            # ... and what it streams with the dequant kernel's own access geometry (the ceiling that means something for this kernel)
+            try:
+                extra["box_stream_gbps"] = box_stream_leg(packed, outs)
+            except Exception as exc:
+                extra["box_stream_gbps"] = {"error": repr(exc)[:200]}
             # the fused decode epilogues at the layer shapes they serve (HBM-cold like the headline): h + o(a), silu(g)*u over the
             # interleaved gate|up weight, h + down(act); same weight traffic as the plain GEMV of that shape
             try:
@@ -969,6 +1006,15 @@ def main():
             line["roofline"]["steady_state_frac"] = round(extra["dequant_stack_of_R_one_launch_gbps"] / HBM_PEAK_GBPS, 4)
             line["roofline_gemv"]["steady_state_gbps"] = extra["gemv_stack_of_R_one_launch_gbps"]
             line["roofline_gemv"]["steady_state_frac"] = round(extra["gemv_stack_of_R_one_launch_gbps"] / HBM_PEAK_GBPS, 4)
+        bs_ = extra.get("box_stream_gbps", {})
+        if "dequant_mix_1r_4w" in bs_:
+            # same run, same buffers, same launch structure, no arithmetic: the dequant's traffic shape as a bare stream
+            line["roofline"]["box_stream_gbps"] = bs_
+            line["roofline"]["frac_of_box_stream"] = round(line["roofline"]["achieved"] / bs_["dequant_mix_1r_4w"], 4)
+            line["roofline"]["box_stream_note"] = ("tools/stream_probe.hip: the dequant kernel's access geometry without arithmetic, R launches, "
+                                                   "HBM-cold, HIP events; frac_of_box_stream = achieved / dequant_mix_1r_4w; `frac` stays against the 8 TB/s spec")
+            line["roofline_gemv"]["frac_of_box_read_stream"] = round(line["roofline_gemv"]["steady_state_gbps"] / bs_["read_only"], 4) \
+                if "steady_state_gbps" in line["roofline_gemv"] else None
         if "dequant_plus_hipblaslt_gemv_us" in extra:
             line["fused_gemv_speedup_vs_dequant_hipblaslt"] = round(extra["dequant_plus_hipblaslt_gemv_us"] / gv_us, 2)
         if world == 1 and not args.no_cpu:

@@ -17,6 +17,9 @@ _TB = {"codebook": TABLE_CODEBOOK, "tree": TABLE_TREE}
 
 
 def build(force: bool = False) -> str:
+    override = os.environ.get("FP4_ORACLE_LIB")  # e.g. the sanitizer build (make -C oracle asan); never set in normal runs
+    if override:
+        return override
     src = os.path.join(_HERE, "fp4_oracle.c")
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
         subprocess.check_call(["make", "-C", _HERE, "-B", "libfp4_oracle.so"], stdout=subprocess.DEVNULL)

@@ -35,6 +35,44 @@ def test_single_gpu_line_schema():
     fe, c4 = rec["fused_epilogue_us"], rec["c4_mistral7b_decode"]
     assert "error" not in fe and fe["gate_up_silu_mul_28672x4096"] > 0 and "error" not in c4, (fe, c4)
     assert c4["row_concat_plus_epilogues"]["graph_ms_per_token"] < c4["separate_launches"]["graph_ms_per_token"]
+    # the same-run streaming ceiling of this box (a measured figure next to the spec peak)
+    bs = r["box_stream_gbps"]
+    assert set(bs) == {"write_only", "read_only", "copy", "dequant_mix_1r_4w"} and all(1000 < v < 8000 for v in bs.values()), bs
+    assert abs(r["frac_of_box_stream"] - r["achieved"] / bs["dequant_mix_1r_4w"]) < 1e-3 and 0.5 < r["frac_of_box_stream"] < 1.5, r
+
+
+def test_the_stream_probe_moves_the_bytes_it_claims():
+    """tools/libfp4_stream_probe.so is a measuring stick: its figure only means something if every launch really touches every byte it
+    is credited with - copy mode reproduces its input, the write modes leave no byte of a sentinel-filled buffer unwritten."""
+    import ctypes
+
+    import torch
+
+    probe = ctypes.CDLL(os.path.join(REPO, "tools", "libfp4_stream_probe.so"))
+    vp, i32, i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
+    probe.fp4_probe_stream.argtypes = [i32, vp, vp, i64, vp]
+    probe.fp4_probe_bytes.argtypes = [i32, i64]
+    probe.fp4_probe_bytes.restype = i64
+    dev = torch.device("cuda", 0)
+    n = 3 * 16384 * 7
+    src = torch.randint(0, 2**31 - 1, (n // 4,), dtype=torch.int32, device=dev)
+    s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    dst = torch.full((n // 4 + 4096,), -1, dtype=torch.int32, device=dev)
+    assert probe.fp4_probe_stream(2, src.data_ptr(), dst.data_ptr(), n, s) == 0
+    assert torch.equal(dst[: n // 4], src) and bool((dst[n // 4:] == -1).all())  # all of it, and nothing past the end
+    for mode in (0, 3):
+        dst.fill_(-1)
+        assert probe.fp4_probe_stream(mode, src.data_ptr(), dst.data_ptr(), n, s) == 0
+        words = dst[: n // 4].view(-1, 4)
+        assert bool((words[:, 1] == 1).all() and (words[:, 2] == 2).all() and (words[:, 3] == 3).all()) and bool((dst[n // 4:] == -1).all())
+        if mode == 3:  # the packed-side words really are read: word 0 of every 16-byte store carries its 4-byte input (+ lane id + store index)
+            lane = (torch.arange(n // 16, device=dev) % 64) + 64 * ((torch.arange(n // 16, device=dev) // 256) % 4)
+            j = (torch.arange(n // 16, device=dev) // 64) % 4
+            assert torch.equal(words[:, 0], (src[: n // 16] + lane.int() + j.int()))
+    assert probe.fp4_probe_stream(1, src.data_ptr(), dst.data_ptr(), n, s) == 0
+    assert probe.fp4_probe_stream(0, None, dst.data_ptr(), n + 16, s) == -1 and probe.fp4_probe_stream(7, None, dst.data_ptr(), n, s) == -1
+    assert probe.fp4_probe_bytes(2, n) == 2 * n and probe.fp4_probe_bytes(3, n) == n + n // 4 and probe.fp4_probe_bytes(1, n) == n
+    torch.cuda.synchronize()
 
 
 def test_two_ranks_self_launched_over_gloo():

@@ -204,3 +204,34 @@ def test_dispatch_table():
              (1, 1, 1, K): "qlinear", (1, 96): "qlinear"}
     for shape, want in cases.items():
         assert o.expected_dispatch(shape, shape[-1], bs) == want, shape
+
+
+def test_oracle_suite_under_asan_ubsan(tmp_path):
+    """The checker checked (sanitizers, CPU build only): oracle/fp4_oracle.c rebuilt with -fsanitize=address,undefined
+    (`make -C oracle asan`) and this file's tests re-run against that library in a child interpreter; an out-of-bounds read in the
+    oracle could otherwise mask a kernel bug.  The first step proves the sanitizer is armed: a deliberately short absmax array MUST be
+    reported (and kill the child), otherwise a clean run below would mean nothing."""
+    import os
+    import subprocess
+    import sys
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if os.environ.get("FP4_ORACLE_LIB"):
+        pytest.skip("already running against an override library (this is the child run)")
+    runtimes = [subprocess.run(["gcc", f"-print-file-name={n}"], capture_output=True, text=True).stdout.strip() for n in ("libasan.so", "libubsan.so")]
+    if not all(os.path.isabs(r) and os.path.exists(r) for r in runtimes):
+        pytest.skip("gcc's sanitizer runtimes are not installed")
+    subprocess.check_call(["make", "-C", os.path.join(repo, "oracle"), "asan"], stdout=subprocess.DEVNULL)
+    lib = os.path.join(repo, "oracle", "_asan", "libfp4_oracle_asan.so")
+    env = dict(os.environ, LD_PRELOAD=":".join(runtimes), ASAN_OPTIONS="detect_leaks=0:abort_on_error=0:exitcode=87", FP4_ORACLE_LIB=lib,
+               OMP_NUM_THREADS="4")
+    armed = tmp_path / "armed.py"
+    armed.write_text(f"import sys; sys.path.insert(0, {repo!r})\n"
+                     "import numpy as np\nfrom oracle import c_oracle\n"
+                     "c_oracle.dequantize(np.zeros(4096, np.uint8), np.ones(3, np.float32), 64, 8192, 'float32')\nprint('no report')\n")
+    p = subprocess.run([sys.executable, str(armed)], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and "heap-buffer-overflow" in p.stderr and "no report" not in p.stdout, (p.returncode, p.stderr[-400:])
+    p = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-p", "no:cacheprovider"], env=env, capture_output=True,
+                       text=True, timeout=900, cwd=repo)
+    assert p.returncode == 0 and "AddressSanitizer" not in p.stderr and "runtime error" not in p.stderr, (p.stdout[-1500:], p.stderr[-1500:])
+    assert " passed" in p.stdout and "failed" not in p.stdout

@@ -138,10 +138,23 @@ def build_torch_ext(force: bool = False) -> str:
     return EXT_LIB
 
 
+PROBE_SRC = os.path.join(REPO, "tools", "stream_probe.hip")
+PROBE_LIB = os.path.join(REPO, "tools", "libfp4_stream_probe.so")
+
+
+def build_stream_probe(force: bool = False) -> str:
+    """bench.py's measuring stick (what this box streams with the dequant kernel's access geometry and no arithmetic): not part of
+    the product, not behind its ABI - but a HIP artefact the bench loads, so it is built with everything else and travels with it."""
+    if force or _stale(PROBE_LIB, [PROBE_SRC, os.path.abspath(__file__)]):
+        _run([_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-shared", "-fPIC", *HIPCC_FLAGS, PROBE_SRC, "-o", PROBE_LIB])
+    return PROBE_LIB
+
+
 def build_all(force: bool = False, ext: bool = True):
     out = [build_hip_lib(force)]
     if ext:
         out.append(build_torch_ext(force))
+    out.append(build_stream_probe(force))
     return out
 
 
