@@ -552,27 +552,35 @@ def c4_leg(dev, tokens=24):
     return out
 
 
-def box_stream_leg(packed, outs):
-    """What THIS box streams, in this very run, with the dequant kernel's own access geometry and no arithmetic (tools/stream_probe.hip:
-    256-thread workgroups, 4 KiB contiguous per wave, 16-byte non-temporal accesses): write only, read only, copy, and the kernel's
-    1-read : 4-write mix, each as R launches of 32 MiB of stores (or loads) rotating over the bench's own buffers - HBM-cold, HIP-graph
-    replay, HIP events, exactly like the headline.  The spec figure (8 TB/s) stays the roofline peak; this says how far the kernel is from
-    what the silicon in front of it delivers for its traffic shape."""
+def _probe_lib():
     probe = ctypes.CDLL(os.path.join(REPO, "tools", "libfp4_stream_probe.so"))
     vp, i32, i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
     probe.fp4_probe_stream.argtypes = [i32, vp, vp, i64, vp]
     probe.fp4_probe_stream.restype = i32
     probe.fp4_probe_bytes.argtypes = [i32, i64]
     probe.fp4_probe_bytes.restype = i64
+    return probe
+
+
+PROBE_MODES = (("write_only", 0), ("read_only", 1), ("copy", 2), ("dequant_mix_1r_4w", 3), ("dequant_mix_1r_4w_loads_barrier_stores", 4))
+
+
+def box_stream_leg(packed, outs):
+    """What THIS box streams, in this very run, with the dequant kernel's own access geometry and no arithmetic (tools/stream_probe.hip:
+    256-thread workgroups, 4 KiB contiguous per wave, 16-byte non-temporal accesses): write only, read only, copy, and the kernel's
+    1-read : 4-write mix, each as R launches of 32 MiB of stores (or loads) rotating over the bench's own buffers - HBM-cold, HIP-graph
+    replay, HIP events, exactly like the headline.  The spec figure (8 TB/s) stays the roofline peak; this says how far the kernel is from
+    what the silicon in front of it delivers for its traffic shape."""
+    probe = _probe_lib()
     R = len(outs)
     n = outs[0].numel() * outs[0].element_size()  # 32 MiB: the output of one 4096x4096 -> bf16 dequant
     assert packed[0].numel() * 4 >= n and n % 16384 == 0
     out = {}
-    for name, mode in (("write_only", 0), ("read_only", 1), ("copy", 2), ("dequant_mix_1r_4w", 3)):
+    for name, mode in PROBE_MODES:
         def run(mode=mode):
             s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
             for i in range(R):
-                src = packed[i] if mode == 3 else outs[(i + R // 2) % R]
+                src = packed[i] if mode >= 3 else outs[(i + R // 2) % R]
                 rc = probe.fp4_probe_stream(mode, src.data_ptr(), outs[i].data_ptr(), n, s)
                 if rc != 0:
                     raise RuntimeError(f"fp4_probe_stream(mode {mode}) failed with code {rc}")
@@ -580,6 +588,33 @@ def box_stream_leg(packed, outs):
         rp = capture(run)
         time_replays(rp, 3, R)
         us = time_replays(rp, 7, R)[0]
+        out[name] = round(probe.fp4_probe_bytes(mode, n) / us / 1e3, 1)
+    return out
+
+
+def box_stream_stack_leg(big_p, big_o):
+    """The same four streams as ONE launch over the stack of R outputs (R x 32 MiB; the copy moves one half of it onto the other): the
+    steady-state counterpart, away from the launch boundary - measured like `dequant_stack_of_R_one_launch_gbps` (four launches per
+    replay, after ~25 ms of the same kernel)."""
+    probe = _probe_lib()
+    total = big_o.numel() * big_o.element_size()
+    assert total % 32768 == 0 and big_p.numel() * 4 >= total
+    out = {}
+    for name, mode in PROBE_MODES:
+        n = total // 2 if mode == 2 else total
+        src = big_p if mode >= 3 else big_o
+        dst_ptr = big_o.data_ptr() + (n if mode == 2 else 0)
+
+        def run():
+            s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+            for _ in range(4):
+                rc = probe.fp4_probe_stream(mode, src.data_ptr(), dst_ptr, n, s)
+                if rc != 0:
+                    raise RuntimeError(f"fp4_probe_stream(mode {mode}) failed with code {rc}")
+
+        rp = capture(run)
+        time_replays(rp, 15, 4)
+        us = time_replays(rp, 9, 4)[0]
         out[name] = round(probe.fp4_probe_bytes(mode, n) / us / 1e3, 1)
     return out
 
@@ -961,6 +996,10 @@ def main():
             time_replays(rp, 20, 12)
             us = time_replays(rp, 9, 12)[0]
             extra["gemv_stack_of_R_one_launch_gbps"] = round(gemv_bytes(R * M, K, BLOCKSIZE, 2) / us / 1e3, 1)
+            try:  # the bare streams of the same geometry over the same stack (steady state of the box, same run)
+                extra["box_stream_stack_of_R_gbps"] = box_stream_stack_leg(big_p, big_o)
+            except Exception as exc:
+                extra["box_stream_stack_of_R_gbps"] = {"error": repr(exc)[:200]}
             del big_p, big_a, big_o, big_y
             # end-to-end through the Python op surface (host overhead visible, like the reference's README table)
             code = lib.pkg.ext.code_table("tree").to(dev)
@@ -1011,10 +1050,14 @@ def main():
             # same run, same buffers, same launch structure, no arithmetic: the dequant's traffic shape as a bare stream
             line["roofline"]["box_stream_gbps"] = bs_
             line["roofline"]["frac_of_box_stream"] = round(line["roofline"]["achieved"] / bs_["dequant_mix_1r_4w"], 4)
+            st_ = extra.get("box_stream_stack_of_R_gbps", {})
+            if "dequant_mix_1r_4w" in st_ and "steady_state_gbps" in line["roofline"]:
+                line["roofline"]["box_stream_stack_of_R_gbps"] = st_
+                line["roofline"]["steady_state_frac_of_box_stream"] = round(line["roofline"]["steady_state_gbps"] / st_["dequant_mix_1r_4w"], 4)
             line["roofline"]["box_stream_note"] = ("tools/stream_probe.hip: the dequant kernel's access geometry without arithmetic, R launches, "
                                                    "HBM-cold, HIP events; frac_of_box_stream = achieved / dequant_mix_1r_4w; `frac` stays against the 8 TB/s spec")
-            line["roofline_gemv"]["frac_of_box_read_stream"] = round(line["roofline_gemv"]["steady_state_gbps"] / bs_["read_only"], 4) \
-                if "steady_state_gbps" in line["roofline_gemv"] else None
+            if "steady_state_gbps" in line["roofline_gemv"] and "read_only" in st_:
+                line["roofline_gemv"]["steady_state_frac_of_box_read_stream"] = round(line["roofline_gemv"]["steady_state_gbps"] / st_["read_only"], 4)
         if "dequant_plus_hipblaslt_gemv_us" in extra:
             line["fused_gemv_speedup_vs_dequant_hipblaslt"] = round(extra["dequant_plus_hipblaslt_gemv_us"] / gv_us, 2)
         if world == 1 and not args.no_cpu:

@@ -12,6 +12,7 @@
 //   mode 1  read only  : 16 B x 4 per lane (same spans, loads)     bytes = n
 //   mode 2  copy       : 16 B x 4 in, 16 B x 4 out                 bytes = 2 n
 //   mode 3  dequant mix: 4 B x 4 in, 16 B x 4 out (1 read : 4 write, the kernel's own ratio without the scales)   bytes = 1.25 n
+//   mode 4  the same mix with the kernel's own phase structure: all loads, one LDS hand-off + workgroup barrier, then the stores
 //
 // hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC tools/stream_probe.hip -o tools/libfp4_stream_probe.so
 #include <hip/hip_runtime.h>
@@ -46,6 +47,15 @@ __global__ __launch_bounds__(kThreads) void stream_probe_kernel(const void *__re
         }
     } else {
         uint32_t q[kLoads] = {0u, 0u, 0u, 0u};
+        if constexpr (MODE == 4) {
+            __shared__ uint32_t s_stage[kThreads];
+            const uint32_t *src = reinterpret_cast<const uint32_t *>(in) + word;
+#pragma unroll
+            for (int j = 0; j < kLoads; ++j) q[j] = __builtin_nontemporal_load(src + j * 64);
+            s_stage[threadIdx.x] = q[0];
+            __syncthreads();
+            acc.y = s_stage[threadIdx.x ^ 1];  // (consumed: word 1 of every store)
+        }
         if constexpr (MODE == 3) {
             const uint32_t *src = reinterpret_cast<const uint32_t *>(in) + word;
 #pragma unroll
@@ -65,16 +75,17 @@ __global__ __launch_bounds__(kThreads) void stream_probe_kernel(const void *__re
 // n = bytes written (modes 0, 2, 3) or read (mode 1) by one launch; must be a multiple of 16 KiB.  `in` needs n bytes (mode 3: n / 4).
 // Returns 0, or -1 for a bad argument, or the hipError_t of the launch.
 extern "C" int fp4_probe_stream(int mode, const void *in, void *out, int64_t n, void *stream) {
-    if (mode < 0 || mode > 3 || n <= 0 || (n % kTileBytes) || !out || (mode != 0 && !in)) return -1;
+    if (mode < 0 || mode > 4 || n <= 0 || (n % kTileBytes) || !out || (mode != 0 && !in)) return -1;
     const dim3 grid((unsigned)(n / kTileBytes)), block(kThreads);
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch (mode) {
         case 0: hipLaunchKernelGGL(stream_probe_kernel<0>, grid, block, 0, s, in, out); break;
         case 1: hipLaunchKernelGGL(stream_probe_kernel<1>, grid, block, 0, s, in, out); break;
         case 2: hipLaunchKernelGGL(stream_probe_kernel<2>, grid, block, 0, s, in, out); break;
+        case 4: hipLaunchKernelGGL(stream_probe_kernel<4>, grid, block, 0, s, in, out); break;
         default: hipLaunchKernelGGL(stream_probe_kernel<3>, grid, block, 0, s, in, out); break;
     }
     return (int)hipGetLastError();
 }
 
-extern "C" int64_t fp4_probe_bytes(int mode, int64_t n) { return mode == 2 ? 2 * n : (mode == 3 ? n + n / 4 : n); }
+extern "C" int64_t fp4_probe_bytes(int mode, int64_t n) { return mode == 2 ? 2 * n : (mode >= 3 ? n + n / 4 : n); }
