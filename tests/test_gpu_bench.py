@@ -38,7 +38,9 @@ def test_single_gpu_line_schema():
     # the same-run streaming ceiling of this box (a measured figure next to the spec peak)
     bs = r["box_stream_gbps"]
     assert set(bs) == {"write_only", "read_only", "copy", "dequant_mix_1r_4w", "dequant_mix_1r_4w_loads_barrier_stores"} and all(1000 < v < 8000 for v in bs.values()), bs
-    assert abs(r["frac_of_box_stream"] - r["achieved"] / bs["dequant_mix_1r_4w"]) < 1e-3 and 0.5 < r["frac_of_box_stream"] < 1.5, r
+    assert abs(r["frac_of_box_stream"] - r["achieved"] / r["box_serial_rw_bound_gbps"]) < 1e-3 and 0.5 < r["frac_of_box_stream"] < 1.5, r
+    assert min(bs["write_only"], bs["read_only"]) <= r["box_serial_rw_bound_gbps"] <= max(bs["write_only"], bs["read_only"])
+    assert set(r["box_stream_stack_of_R_gbps"]) == set(bs) and 0.5 < r["steady_state_frac_of_box_stream"] < 1.5, r
 
 
 def test_the_stream_probe_moves_the_bytes_it_claims():
