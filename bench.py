@@ -221,7 +221,7 @@ class Watchdog:
         if self.provisional is not None:
             line = dict(self.provisional)
             line["incomplete"] = f"deadline of {self.seconds:.0f} s passed in stage '{self.stage}': figures after the timed region are missing"
-            print(json.dumps(line), flush=True)
+            print_result(line)
         os._exit(124)
 
     def cancel(self):
@@ -229,6 +229,26 @@ class Watchdog:
 
 
 _WATCHDOG = None
+_RESULT_OUT = None  # the process's ORIGINAL stdout, kept for the one result line (claim_stdout)
+
+
+def claim_stdout():
+    """stdout carries ONE JSON line - but native libraries write there too: RCCL prints a five-line version banner ("RCCL version : ...",
+    "HIP version : ...", host name ...) on stdout when its first communicator comes up, gloo prints "[Gloo] Rank N is connected ..."
+    (found with the one-rank RCCL rehearsal of round 4: a reader taking "the line on stdout" would have met the banner first).  So the
+    worker keeps a private duplicate of the original stdout for its result line and points file descriptor 1 at stderr for everybody
+    else - C-level printf included - before anything initialises the GPU or a process group."""
+    global _RESULT_OUT
+    if _RESULT_OUT is None:
+        sys.stdout.flush()
+        _RESULT_OUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+    return _RESULT_OUT
+
+
+def print_result(line):
+    out = _RESULT_OUT or sys.stdout
+    print(json.dumps(line), file=out, flush=True)
 
 
 def _kill_group(proc, grace_s=5.0):
@@ -472,7 +492,8 @@ def c5_leg(dist, backend, rank, world, dev, barrier, tokens=16):
             out["oneshot_selfcheck"] = {"ok": False, "error": repr(exc)[:300], **_ipc_env()}
     for ar, graph in modes:
         try:
-            token, h0, meta = db.build_token_fn(cfg, dev, torch.bfloat16, world, rank, allreduce=ar, lm_head=False, epilogues=True)
+            token, h0, meta = db.build_token_fn(cfg, dev, torch.bfloat16, world, rank, allreduce=ar, lm_head=False, epilogues=True,
+                                                tensor_parallel=True)
             t = db.time_tokens(token, h0, tokens, graph=graph, barrier=barrier)
             best = t["graph_s"] or t["eager_s"]
             out[ar] = {"eager_ms_per_token": round(t["eager_s"] * 1e3, 3),
@@ -749,8 +770,16 @@ def main():
         sys.exit(launch_workers(args.gpus, sys.argv[1:], deadline_s=args.deadline))
     if args.gpus != world:
         sys.exit(f"--gpus {args.gpus} does not match WORLD_SIZE={world}")
+    claim_stdout()  # from here on file descriptor 1 is stderr for everyone but print_result()
     # one rank per GPU; FP4_BENCH_BACKEND=gloo lets the N > 1 code path be rehearsed on a box with fewer GPUs
     backend = os.environ.get("FP4_BENCH_BACKEND", "nccl")
+    # FP4_BENCH_FORCE_GROUP=1: take the whole N > 1 code path (process group, group evidence, per-rank gather, K-split / strong-split /
+    # C5 legs) with ONE rank - the only way to run that path through real RCCL on a one-GPU box (RCCL refuses two ranks on one device)
+    grouped = world > 1 or os.environ.get("FP4_BENCH_FORCE_GROUP") == "1"
+    if grouped and "MASTER_ADDR" not in os.environ:  # plain `python bench.py` with the switch: a rendezvous of our own
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(sk.getsockname()[1]), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
     ndev = torch.cuda.device_count()
     if world > 1 and backend == "nccl" and ndev < world:
         sys.exit(f"--gpus {world} needs {world} visible GPUs for the RCCL backend, found {ndev} "
@@ -763,7 +792,7 @@ def main():
     own = float(os.environ["FP4_BENCH_DEADLINE_S"]) - 15.0 if "FP4_BENCH_DEADLINE_S" in os.environ else args.deadline
     _WATCHDOG = Watchdog(max(5.0, own), rank)
     stage("started")
-    if world > 1:
+    if grouped:
         import datetime
 
         import torch.distributed as dist
@@ -780,7 +809,7 @@ def main():
         except Exception as exc:
             print(f"bench.py: rank {rank}: process-group initialisation ({backend}) failed: {type(exc).__name__}: {exc}", file=sys.stderr, flush=True)
             raise
-    proof = group_proof(dist, backend, rank, world, local, dev) if world > 1 else None
+    proof = group_proof(dist, backend, rank, world, local, dev) if grouped else None
     stage("process-group-ready")
 
     lib = Lib()
@@ -809,7 +838,7 @@ def main():
         stage("buffers-ready")
 
         def barrier():
-            if world > 1:
+            if grouped:
                 dist.barrier()
             torch.cuda.synchronize()
 
@@ -833,7 +862,7 @@ def main():
 
         times = torch.tensor([wall, dq_total_s, gv_total_s], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         per_rank = None
-        if world > 1:
+        if grouped:
             mine = torch.tensor([dq_total_s, gv_total_s], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
             got = [torch.empty_like(mine) for _ in range(world)]
             dist.all_gather(got, mine)  # every rank's own event-timed totals: stragglers show as a spread, not only as the MAX
@@ -900,7 +929,7 @@ def main():
                 q = statistics.quantiles(us, n=4) if len(us) >= 4 else [us[0], us[len(us) // 2], us[-1]]
                 return {"median_us": round(q[1], 3), "iqr_us": round(q[2] - q[0], 3), "min_us": round(us[0], 3), "max_us": round(us[-1], 3)}
 
-            if world > 1:
+            if grouped:
                 # row e evidence: who took part (real collectives on the data-path backend) and how evenly the ranks ran
                 line["group"] = proof
                 dq_rates = [dq_b * dq_launches / t[0] / 1e9 for t in per_rank]
@@ -918,7 +947,7 @@ def main():
 
         # ---- secondary figures (outside the timed region) ------------------------------------
         extra = {}
-        if world > 1:
+        if grouped:
             try:
                 extra["tp_ksplit"] = tp_ksplit_leg(lib, dist, backend, rank, world, dev, x, packed[0], absmax[0], barrier)
             except Exception as exc:  # never let the optional leg take the headline line down
@@ -1076,8 +1105,8 @@ def main():
         if world == 1 and not args.no_cpu:
             line["cpu_baseline"] = cpu_baseline()
         _WATCHDOG.provisional = None
-        print(json.dumps(line), flush=True)
-    if world > 1:
+        print_result(line)
+    if grouped:
         dist.barrier()
         dist.destroy_process_group()
     stage("done")

@@ -272,3 +272,27 @@ def test_result_line_is_recovered_when_another_process_glues_text_to_it():
     assert got == {"metric": "m", "value": 1.5, "nested": {"a": [1, 2]}}
     src = open(os.path.join(REPO, "bench.py")).read()
     assert "raw_decode(txt[at:])" in src  # the rule above is the one launch_workers applies
+
+
+def test_native_chatter_on_stdout_cannot_reach_the_result_stream(tmp_path):
+    """RCCL prints a version banner and gloo prints connection notes on file descriptor 1 from native code; after bench.claim_stdout()
+    that descriptor is stderr for everybody, and only bench.print_result() still reaches the process's original stdout."""
+    import subprocess
+
+    worker = _script(tmp_path, f"""
+        import os, sys
+        sys.path.insert(0, {REPO!r})
+        import bench
+        bench.claim_stdout()
+        os.write(1, b"RCCL version : 2.26.6-HEAD (native printf)\\n")
+        print("python-level chatter")
+        os.system("echo child process chatter")
+        bench.print_result({{"metric": "stand-in", "value": 2.5}})
+        bench.claim_stdout()  # idempotent
+        bench.print_result({{"metric": "second"}})
+    """)
+    p = subprocess.run([sys.executable, worker], capture_output=True, text=True, timeout=200)
+    assert p.returncode == 0, p.stderr[-800:]
+    assert [json.loads(l)["metric"] for l in p.stdout.splitlines()] == ["stand-in", "second"], p.stdout
+    for text in ("RCCL version", "python-level chatter", "child process chatter"):
+        assert text in p.stderr and text not in p.stdout

@@ -119,12 +119,10 @@ def test_two_ranks_started_the_way_the_driver_starts_them():
            "--master-port", str(port), os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--matrices", "8"]
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=REPO)
     assert p.returncode == 0, p.stderr[-3000:]
-    # stdout carries ONE result line; the only other text allowed is gloo's own "[Gloo] Rank N is connected ..." chatter of the
-    # rehearsal backend (printed by both ranks at once, so it can arrive torn across lines) - RCCL prints nothing of the kind
-    lines = [l for l in p.stdout.splitlines() if '{"metric"' in l]
+    # stdout carries ONE result line and nothing else: gloo's "[Gloo] Rank N is connected ..." chatter (and, with the nccl backend, RCCL's
+    # version banner) are written to file descriptor 1 by native code - bench.claim_stdout() has pointed that at stderr by then
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
     assert len(lines) == 1 and lines[0].startswith('{"metric"'), p.stdout[-3000:]
-    rest = [l for l in p.stdout.splitlines() if l.strip() and '{"metric"' not in l]
-    assert all("Gloo" in l or "peer ranks" in l for l in rest), rest
     rec = json.loads(lines[0])
     assert SCHEMA <= set(rec) and rec["n_gpus"] == 2 and "incomplete" not in rec
     assert all(r["hsa_ipc_env_at_start"] is None for r in rec["group"]["ranks"]), rec["group"]["ranks"]  # nothing was preset: the default did it
@@ -133,3 +131,23 @@ def test_two_ranks_started_the_way_the_driver_starts_them():
         assert "error" not in rec[leg], rec[leg]
     c5 = rec["c5_llama3_8b_tp"]
     assert "error" not in c5["dist"] and "error" not in c5.get("oneshot", {}), c5
+
+
+def test_the_group_path_through_real_rccl_with_one_rank():
+    """RCCL refuses two ranks on one device, so a one-GPU box can only run the N > 1 code path through the REAL `nccl` backend with one
+    rank: FP4_BENCH_FORCE_GROUP=1 makes bench.py take that path anyway - init_process_group("nccl", device_id=...), the `group` evidence
+    (int64 sum / MIN, all_gather_object, an f32 sum, all on device tensors), the float64 all_gather of the per-rank totals, the barriers,
+    the K-split leg's eager all-reduces, the strong-split MAX reduce and the C5 leg on the tensor-parallel modules - every collective call
+    and dtype the 8-GPU run will issue, issued once through RCCL itself (what gloo rehearsals cannot show)."""
+    rec = _run(["--steps", "2", "--warmup", "1", "--matrices", "8", "--no-cpu"],
+               {"FP4_BENCH_FORCE_GROUP": "1", "FP4_BENCH_C5_LAYERS": "2", "FP4_BENCH_C4": "0"})
+    g = rec["group"]
+    assert g["backend"] == "nccl" and g["collective_library"].startswith("RCCL 2."), g
+    assert g["ranks_seen"] == 1 and g["rank_checksum"] == 1 and g["allreduce_data_ok_on_every_rank"] and g["distinct_devices"] == 1 and g["ok"], g
+    assert rec["n_gpus"] == 1 and len(rec["per_rank"]["dequant_gbps"]) == 1
+    assert abs(rec["per_rank"]["dequant_gbps"][0] - rec["value"]) <= 0.01 * rec["value"]
+    assert "error" not in rec["tp_ksplit"] and rec["tp_ksplit"]["allreduce_16KiB_f32_us"] > 0, rec["tp_ksplit"]
+    assert "error" not in rec["strong_scaling_row_split"] and rec["strong_scaling_row_split"]["rows_per_gpu"] == 4096
+    c5 = rec["c5_llama3_8b_tp"]
+    assert c5["backend"] == "nccl" and c5["oneshot_selfcheck"]["ok"] is True and "error" not in c5["dist"], c5
+    assert c5["allreduces_per_token"] == 4 and "error" not in c5.get("oneshot", {}), c5

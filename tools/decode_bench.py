@@ -41,17 +41,19 @@ def fp4_bytes(m, k):
 
 
 def build_token_fn(cfg, dev, dtype, world=1, rank=0, group=None, fuse=False, epilogues=False, batch=1,
-                   reference_dispatch=False, allreduce="dist", lm_head=True, seed=7, lean_glue=False):
+                   reference_dispatch=False, allreduce="dist", lm_head=True, seed=7, lean_glue=False, tensor_parallel=None):
     """Builds the FP4 layers of a `cfg`-shaped decoder and returns (token_fn, h0, meta).
 
     world == 1: QuantData dispatchers (the product's single-GPU path).  world > 1: Column/RowParallelFP4Linear
     (q/k/v/gate/up M-split without a gather, o/down K-split with one f32 all-reduce each: 2 all-reduces per layer).
     fuse: q|k|v and gate|up as one launch each (row concatenation).  epilogues: on top of that, silu(gate)*up and the
-    residual adds run in the GEMV epilogue (torch_bnb_fp4.fused)."""
+    residual adds run in the GEMV epilogue (torch_bnb_fp4.fused).  tensor_parallel: None = (world > 1); True builds the tensor-parallel
+    modules even for a one-rank group (bench.py's FP4_BENCH_FORCE_GROUP rehearsal of the N > 1 path through real RCCL on one GPU)."""
     import torch_bnb_fp4 as pkg
     from torch_bnb_fp4 import parallel as par
 
     H, KV, I, V, L = cfg["hidden"], cfg["kv"], cfg["inter"], cfg["vocab"], cfg["layers"]
+    tp = world > 1 if tensor_parallel is None else bool(tensor_parallel)
     gen = torch.Generator(device=dev).manual_seed(seed)  # the same full weights on every rank; the modules shard them
 
     def fp4_weight(m, k):
@@ -71,7 +73,7 @@ def build_token_fn(cfg, dev, dtype, world=1, rank=0, group=None, fuse=False, epi
             packed, absmax, (m, k) = par.concat_rows([(*fp4_weight(mi, k), (mi, k)) for mi in m], BS)
         else:
             packed, absmax = fp4_weight(m, k)
-        if world == 1:
+        if not tp:
             return qd_of(packed, absmax, m, k).forward
         if kind == "col":
             return par.ColumnParallelFP4Linear(packed, absmax, (m, k), BS, group=group, gather_output=False)
@@ -79,17 +81,17 @@ def build_token_fn(cfg, dev, dtype, world=1, rank=0, group=None, fuse=False, epi
 
     layers = []
     for _ in range(L):
-        if epilogues and world == 1:
+        if epilogues and not tp:
             from torch_bnb_fp4 import fused
 
             ly = dict(qkv=linear([H, KV, KV], H, "col"),
                       o=fused.FusedFP4Linear.from_packed(*fp4_weight(H, H), (H, H), BS),
                       gate_up=fused.FusedFP4Linear.gate_up_from_packed(fp4_weight(I, H), fp4_weight(I, H), (I, H), BS),
                       down=fused.FusedFP4Linear.from_packed(*fp4_weight(H, I), (H, I), BS))
-        elif fuse and world == 1:
+        elif fuse and not tp:
             ly = dict(qkv=linear([H, KV, KV], H, "col"), o=linear(H, H, "row"), gate_up=linear([I, I], H, "col"),
                       down=linear(H, I, "row"))
-        elif (fuse or epilogues) and world > 1:
+        elif (fuse or epilogues) and tp:
             # tensor parallel with the same fusions: q|k|v shards in one launch, gate|up shards interleaved with silu(g)*u in the
             # epilogue, the residual adds inside the K-split layers (in the one-shot all-reduce's epilogue when that is used)
             w = lambda m, k: (*fp4_weight(m, k), (m, k))
@@ -125,7 +127,7 @@ def build_token_fn(cfg, dev, dtype, world=1, rank=0, group=None, fuse=False, epi
                 h = ly["down"](ly["tp_gate_up"](h), residual=h)
                 h = h * rescale if rescale != 1.0 else h
                 continue
-            if "gate_up" in ly and epilogues and world == 1:
+            if "gate_up" in ly and epilogues and not tp:
                 q, k, v = ly["qkv"](h).split([H, KV, KV], dim=-1)
                 a = attn(q, k, v)
                 h = ly["o"](a.contiguous(), residual=h)       # h + o(a), one launch
@@ -150,7 +152,7 @@ def build_token_fn(cfg, dev, dtype, world=1, rank=0, group=None, fuse=False, epi
     per_token_fp4 = L * (2 * fp4_bytes(H, H) + 2 * fp4_bytes(KV, H) + 2 * fp4_bytes(I, H) + fp4_bytes(H, I)) // world
     meta = dict(layers=L, fp4_bytes_per_token_per_gpu=per_token_fp4, lm_head_bytes=(V * H * 2 if lm_head else 0),
                 fp4_linear_calls_per_token=(4 if (fuse or epilogues) else 7) * L,
-                allreduces_per_token=(2 * L if world > 1 else 0))
+                allreduces_per_token=(2 * L if tp else 0))
     return token, h0, meta
 
 
@@ -218,6 +220,11 @@ def main():
     if args.layers:
         cfg["layers"] = args.layers
     world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
+    # RCCL (version banner) and gloo (connection notes) print on file descriptor 1 from native code: keep the original stdout for the
+    # result line, point descriptor 1 at stderr for everything else (same as bench.claim_stdout)
+    sys.stdout.flush()
+    result_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     backend = os.environ.get("FP4_BENCH_BACKEND", "nccl")
     local_dev = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_dev)
@@ -259,7 +266,7 @@ def main():
             "tokens_per_s": round(args.batch / best, 1), "fp4_stream_gbps_per_gpu": round(per_token_fp4 / best / 1e9, 1),
             "hbm_floor_ms_per_token_at_8TBps": round((per_token_fp4 + meta["lm_head_bytes"]) / 8e12 * 1e3, 3),
             "data": "synthetic random FP4 bytes + scales; attention replaced by identity; lm_head dense " + args.dtype,
-        }))
+        }), file=result_out, flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
