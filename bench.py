@@ -240,9 +240,13 @@ def claim_stdout():
     else - C-level printf included - before anything initialises the GPU or a process group."""
     global _RESULT_OUT
     if _RESULT_OUT is None:
-        sys.stdout.flush()
-        _RESULT_OUT = os.fdopen(os.dup(1), "w")
-        os.dup2(2, 1)
+        try:
+            sys.stdout.flush()
+            keep = os.dup(1)
+            os.dup2(2, 1)
+            _RESULT_OUT = os.fdopen(keep, "w")
+        except OSError:  # no usable stdout / stderr descriptor (a caller that closed them): print where print goes, as before
+            _RESULT_OUT = sys.stdout
     return _RESULT_OUT
 
 
