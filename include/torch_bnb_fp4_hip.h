@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FP4_HIP_ABI_VERSION 6
+#define FP4_HIP_ABI_VERSION 7
 #define FP4_HIP_API __attribute__((visibility("default")))
 
 /* Element types, numbered like the reference's ScalarTypeEnum (csrc/torch_fp4.cpp:22-26). */

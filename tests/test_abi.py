@@ -27,7 +27,7 @@ def test_header_symbols_are_exported():
 def test_abi_version_and_tables():
     l = hipabi.lib()
     header = open(hipabi.HEADER).read()
-    assert l.fp4_hip_abi_version() == int(header.split('#define FP4_HIP_ABI_VERSION')[1].split()[0]) == 6
+    assert l.fp4_hip_abi_version() == int(header.split('#define FP4_HIP_ABI_VERSION')[1].split()[0]) == 7
     for which, tab in ((hipabi.TABLE_CODEBOOK, o.CODEBOOK_TABLE), (hipabi.TABLE_TREE, o.TREE_TABLE)):
         out = np.zeros(16, np.float32)
         assert l.fp4_hip_code_table(which, out.ctypes.data_as(ctypes.c_void_p)) == hipabi.OK
