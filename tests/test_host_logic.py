@@ -351,3 +351,39 @@ def test_save_fp4_model_dtype_metadata_and_tensor_parallel_guard(monkeypatch, tm
                 ser.save_fp4_model(nn.Sequential(nn.Linear(4, 4), layer), str(tmp_path / "tp.safetensors"))
     finally:
         dist.destroy_process_group()
+
+
+def test_tools_and_bench_keep_away_from_the_oracle():
+    """The oracle is test infrastructure: besides tests/, only __graft_entry__.smoke() and bench.py's `cpu_baseline` leg may touch it.
+    tools/ (sweeps, decode harnesses, experiments) must not import it at all; bench.py exactly once, inside cpu_baseline()."""
+    import ast
+    import os
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(pkg.__file__)))
+    repo = os.path.dirname(repo) if os.path.basename(repo) == "torch-bnb-fp4_amd" else repo
+    tools = os.path.join(repo, "tools")
+
+    def oracle_imports(path):
+        found = []
+        tree = ast.parse(open(path).read())
+        parents = {}
+        for node in ast.walk(tree):
+            for child in ast.iter_child_nodes(node):
+                parents[child] = node
+        for node in ast.walk(tree):
+            names = []
+            if isinstance(node, ast.Import):
+                names = [a.name for a in node.names]
+            elif isinstance(node, ast.ImportFrom):
+                names = [node.module or ""]
+            if any(n == "oracle" or n.startswith("oracle.") for n in names):
+                fn = node
+                while fn in parents and not isinstance(fn, (ast.FunctionDef, ast.AsyncFunctionDef)):
+                    fn = parents[fn]
+                found.append(fn.name if isinstance(fn, (ast.FunctionDef, ast.AsyncFunctionDef)) else "<module>")
+        return found
+
+    for f in sorted(os.listdir(tools)):
+        if f.endswith(".py"):
+            assert oracle_imports(os.path.join(tools, f)) == [], f
+    assert oracle_imports(os.path.join(repo, "bench.py")) == ["cpu_baseline"]

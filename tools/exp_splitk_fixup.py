@@ -4,8 +4,10 @@ conclusion: profiles/r04_splitk_single_launch_fixup_attempt.txt.)
 
 Round-4 experiment: 9..64 activation rows on short weights - the x-stationary split-K kernel as ONE launch with a last-arriver
 fix-up (fp4_hip_set_variant("gemm_splitk", 1)) against the default dispatch of fp4_hip_gemm_small_ws, HBM-cold, HIP-graph replay.
-Every fix-up output is first checked against the float64 product of the exact weights (the GEMV's bar), three launches in a row on
-one workspace (the counters must come back to zero by themselves)."""
+Every fix-up output is first compared with the default dispatch's output for the same operands (parity-tested kernels; both round a
+float32 sum of the same products once, so they may differ by one bf16 ulp where the summation order matters), three launches in a row on
+one workspace (the counters must come back to zero by themselves).  The runs recorded in profiles/ checked against the float64 product
+through the test-side oracle; tools/ must not import it, so the committed script does not."""
 import ctypes
 import os
 import statistics
@@ -16,7 +18,6 @@ sys.path[:0] = [REPO, os.path.join(REPO, "torch-bnb-fp4_amd"), os.path.join(REPO
 import torch  # noqa: E402
 
 import hipabi  # noqa: E402
-from oracle import torch_cpu  # noqa: E402
 
 dev = torch.device("cuda", 0)
 BS = 64
@@ -61,26 +62,21 @@ def ws_bytes(B, M, K):
 shapes = [(4096, 4096), (6144, 4096), (1024, 4096), (4096, 14336), (4096, 11008), (5120, 13824), (4096, 8192)]
 if len(sys.argv) > 2:
     shapes = [(int(sys.argv[1]), int(sys.argv[2]))]
-table = torch_cpu.code_table("codebook").to(dev)
 for M, K in shapes:
     n = M * K
     R = max(6, min(48, int(1.0e9 / (n * 0.5625))))
     gen = torch.Generator(device=dev).manual_seed(0)
     packed = [torch.randint(0, 256, (n // 2,), dtype=torch.uint8, device=dev, generator=gen) for _ in range(R)]
     absmax = [torch.rand(n // 64, device=dev, generator=gen) * 0.1 + 0.01 for _ in range(R)]
-    w64 = torch_cpu.dequantize(packed[0], absmax[0], M, K, BS, torch.float32, table).double()
     for B in (9, 12, 16, 24, 32, 48, 64):
         x = torch.randn(B, K, device=dev).to(torch.bfloat16)
-        exact = x.double() @ w64.t()
-        scale = x.double().abs() @ w64.abs().t()
-        tol = 2.0 ** -8 * 1.01 * exact.abs() + 1e-5 * scale
         out = torch.empty(B, M, dtype=torch.bfloat16, device=dev)
         # default dispatch (with the workspace it asks for, if any)
         hipabi.set_variant("gemm_splitk", 0)
         nb0 = ws_bytes(B, M, K)
         ws0 = torch.empty(max(nb0, 16), dtype=torch.uint8, device=dev) if nb0 else None
         ws_call(x, packed[0], absmax[0], M, K, out, ws0)
-        assert bool(((out.double() - exact).abs() <= tol).all())
+        ref = out.clone()
         t_def = timeit(capture(lambda: [ws_call(x, packed[i], absmax[i], M, K, out, ws0) for i in range(R)]), R)
         # single launch with the fix-up (FIXUP_MODE: 1 = no fences, 3 = release fence, 5 = acquire fence, 7 = both)
         hipabi.set_variant("gemm_splitk", int(os.environ.get("FIXUP_MODE", "1")))
@@ -94,7 +90,7 @@ for M, K in shapes:
                 ws_call(x, packed[0], absmax[0], M, K, o, ws1)
                 outs.append(o)
             torch.cuda.synchronize()
-            bad = int(((outs[0].double() - exact).abs() > tol).sum().item())
+            bad = int(((outs[0].float() - ref.float()).abs() > 2.0 ** -7 * ref.float().abs() + 1e-3).sum().item())
             same = torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
             counters_zero = bool((ws1[: ((M + 15) // 16 * 4 + 255) // 256 * 256] == 0).all())
             t_fix = timeit(capture(lambda: [ws_call(x, packed[i], absmax[i], M, K, out, ws1) for i in range(R)]), R)
@@ -103,5 +99,5 @@ for M, K in shapes:
             line += "   fix-up: n/a"
         hipabi.set_variant("gemm_splitk", 0)
         print(line, flush=True)
-    del packed, absmax, w64
+    del packed, absmax
     torch.cuda.empty_cache()
