@@ -141,6 +141,38 @@ def _worker(rank, world, port, q):
             res["after_timeout"] = (bool((y2.float() == 2.0).all().item()), lonely.status())
         dist.barrier()
         lonely.close()
+        # set-up failures are collective: rank 1 cannot map rank 0's buffer (injected) -> BOTH ranks raise at once, naming rank 1, and
+        # nothing is left mapped or allocated; the same for a slot buffer that cannot be allocated on rank 0
+        import time
+
+        class FailingExt:
+            def __init__(self, real, what):
+                self._real, self._what = real, what
+
+            def __getattr__(self, name):
+                if name == self._what:
+                    def boom(*a, **k):
+                        raise RuntimeError("injected failure of " + name)
+                    return boom
+                return getattr(self._real, name)
+
+        real_ext = comm_mod.ext
+        for what, bad_rank in (("comm_open", 1), ("comm_alloc", 0)):
+            if rank == bad_rank:
+                comm_mod.ext = FailingExt(real_ext, what)
+            t0 = time.monotonic()
+            try:
+                comm_mod.OneShotAllReduce(None, capacity=1024)
+                outcome = "no error raised"
+            except RuntimeError as exc:
+                outcome = str(exc)
+            finally:
+                comm_mod.ext = real_ext
+            took = time.monotonic() - t0
+            assert f"rank {bad_rank}" in outcome and "injected failure of " + what in outcome and took < 30, (rank, what, outcome, took)
+            if rank == 0:
+                res["collective_failure_" + what] = outcome
+            dist.barrier()
         if rank == 0:
             q.put(res)
         dist.barrier()
@@ -185,3 +217,6 @@ def test_tensor_parallel_two_ranks_on_one_gpu():
     # check() clears what it reports (fp4_hip_comm_clear_status): epoch kept, status word and lane count back to zero
     assert res["status_after_check"] == (1, 0, 0, 0), res["status_after_check"]
     assert res["after_timeout"] == (True, (2, 0, 0, 0)), res["after_timeout"]
+    # a set-up failure on one rank is the same, immediate error on every rank (both ranks assert it in the worker; rank 0's text here)
+    assert "rank 1: mapping rank 0's buffer failed" in res["collective_failure_comm_open"], res["collective_failure_comm_open"]
+    assert "rank 0: allocating / exporting the slot buffer failed" in res["collective_failure_comm_alloc"], res["collective_failure_comm_alloc"]

@@ -52,10 +52,25 @@ class OneShotAllReduce:
         self.capacity = int(capacity)
         self.timeout_us = int(timeout_us)
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-        self._own, handle, kind = ext.comm_alloc(self.world, self.capacity, self.device.index)
+        # (set-up failures are made COLLECTIVE: what goes wrong on one rank is raised on every rank at once, never one exception here and
+        #  the other ranks parked in the next collective until the process group's time-out)
+        try:
+            self._own, handle, kind = ext.comm_alloc(self.world, self.capacity, self.device.index)
+            alloc_problem = None
+        except Exception as exc:
+            self._own, handle, kind, alloc_problem = None, b"", -1, f"allocating / exporting the slot buffer failed: {exc}"
         self.memory_kind = _KINDS.get(kind, str(kind))
         handles = [None] * self.world
-        dist.all_gather_object(handles, (self.rank, os.getpid(), bytes(handle), _device_identity(self.device), self.memory_kind), group=group)
+        dist.all_gather_object(handles, (self.rank, os.getpid(), bytes(handle), _device_identity(self.device), self.memory_kind, alloc_problem),
+                               group=group)
+        failed = [(r, why) for r, _, _, _, _, why in handles if why]
+        if failed:
+            if self._own is not None:
+                ext.comm_free(self._own)
+                self._own = None
+            raise RuntimeError("OneShotAllReduce: " + "; ".join(f"rank {r}: {why}" for r, why in failed)
+                               + f" (HSA_ENABLE_IPC_MODE_LEGACY={os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')!r} in this process). Use allreduce='dist' (RCCL)")
+        handles = [h[:5] for h in handles]
         other_devices = sorted({r for r, _, _, ident, _ in handles if ident != _device_identity(self.device)})
         plain = sorted({r for r, _, _, _, k in handles if k == "default"})
         if other_devices and plain and os.environ.get("FP4_COMM_ALLOC") != "default":
@@ -65,16 +80,42 @@ class OneShotAllReduce:
                                f"'{self.memory_kind}') and the group spans several devices (peers of rank {self.rank} on other devices: "
                                f"{other_devices}): peer-written slots may be served stale from the owner's L2.  Use allreduce='dist' "
                                "(RCCL), or set FP4_COMM_ALLOC=default to accept time-outs / NaN as the failure mode")
+        # Mapping the peers' buffers is the step that has never run across devices (one-GPU boxes only): a failure on ONE rank must
+        # become the same, immediate error on EVERY rank - not one exception here and seven ranks parked in the barrier below until
+        # the process group's time-out.  So every rank reports how its mappings went before anybody proceeds.
         self._peers, self._opened = [], []
+        problem = None
         for r, pid, h, _, _ in handles:
             if r == self.rank:
                 self._peers.append(self._own)
             elif pid == os.getpid():
-                raise RuntimeError("OneShotAllReduce: two ranks in one process cannot share an IPC handle")
+                problem = problem or "two ranks in one process cannot share an IPC handle"
+                self._peers.append(0)
             else:
-                p = ext.comm_open(h, self.device.index)
+                try:
+                    p = ext.comm_open(h, self.device.index)
+                except Exception as exc:  # hipIpcOpenMemHandle refused (peer access, IPC mode, driver): reported collectively below
+                    problem = problem or f"mapping rank {r}'s buffer failed: {exc}"
+                    self._peers.append(0)
+                    continue
                 self._peers.append(p)
                 self._opened.append(p)
+        reports = [None] * self.world
+        dist.all_gather_object(reports, (self.rank, problem), group=group)
+        failed = [(r, why) for r, why in reports if why]
+        if failed:
+            for p in self._opened:
+                try:
+                    ext.comm_close(p)
+                except Exception:
+                    pass
+            dist.barrier(group=group)  # every peer has unmapped our buffer before it is freed
+            ext.comm_free(self._own)
+            self._own, self._peers, self._opened = None, [], []
+            raise RuntimeError("OneShotAllReduce: the peer buffers could not be mapped on every rank ("
+                               + "; ".join(f"rank {r}: {why}" for r, why in failed)
+                               + f"); HSA_ENABLE_IPC_MODE_LEGACY={os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')!r} in this process. "
+                               "Use allreduce='dist' (RCCL)")
         dist.barrier(group=group)  # nobody starts reducing before every buffer is mapped everywhere
 
     def reduce(self, partial: torch.Tensor, out_dtype: torch.dtype, bias: Optional[torch.Tensor] = None,
