@@ -813,7 +813,12 @@ def main():
         except Exception as exc:
             print(f"bench.py: rank {rank}: process-group initialisation ({backend}) failed: {type(exc).__name__}: {exc}", file=sys.stderr, flush=True)
             raise
-    proof = group_proof(dist, backend, rank, world, local, dev) if grouped else None
+    proof = None
+    if grouped:
+        try:
+            proof = group_proof(dist, backend, rank, world, local, dev)
+        except Exception as exc:  # (an error every rank meets alike must not cost the headline; a one-rank failure ends in the time-outs)
+            proof = {"ok": False, "error": repr(exc)[:300]}
     stage("process-group-ready")
 
     lib = Lib()
