@@ -17,6 +17,16 @@ rank 0 prints ONE JSON line.  `value` = whole-job dequant GB/s (algorithmic byte
 in HBM); the GEMV figures, the HIP-event roofline of the dequant kernel and a pure-torch CPU
 dequant baseline timed on the host cores ride along in the same line.  No data-path collective:
 rows of W are independent, so ranks process independent shards (weak scaling).
+
+stdout carries the ONE JSON line and nothing else (claim_stdout: RCCL's version banner, gloo's notes and every other print go to stderr).
+
+Environment switches (all optional; none changes the timed region):
+  FP4_BENCH_BACKEND=gloo      N > 1 with the ranks SHARING devices and gloo standing in for RCCL (one-GPU rehearsal of the N > 1 path)
+  FP4_BENCH_FORCE_GROUP=1     take the N > 1 code path with one rank (the only way through real RCCL on a one-GPU box)
+  FP4_BENCH_C4=0 / FP4_BENCH_C4_LAYERS=n      skip / shorten the Mistral-7B decode leg (N = 1)
+  FP4_BENCH_C5=0 / FP4_BENCH_C5_LAYERS=n      skip / shorten the Llama-3-8B tensor-parallel leg (N > 1)
+  FP4_BENCH_C5_ONESHOT=0      leave the one-shot all-reduce out of that leg;  FP4_BENCH_C5_GRAPH=1  also capture the RCCL variant in a HIP graph
+  FP4_BENCH_CPU_THREADS=n     cap the host threads of the cpu_baseline leg (default: the cgroup's share, at most 64)
 """
 from __future__ import annotations
 
