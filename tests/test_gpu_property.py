@@ -52,3 +52,49 @@ def test_gemv_any_shape(M, kc, bs, dt, bias, seed):
     scale = np.abs(o.dequantize_f32(packed, am, bs, M * K).reshape(M, K).astype(np.float64)) @ np.abs(xv)
     half_ulp = {torch.bfloat16: 2.0**-8, torch.float16: 2.0**-11, torch.float32: 0.0}[dt]
     assert (np.abs(y.float().cpu().numpy() - exact) <= half_ulp * 1.01 * np.abs(exact) + 1e-5 * scale + 1e-30).all()
+
+
+@settings(max_examples=150, **COMMON)
+@given(M=st.integers(1, 40000), kc=st.integers(1, 512), dt=st.sampled_from(DT), bias=st.booleans(), seed=st.integers(0, 2**31))
+def test_gemv_any_large_shape(M, kc, dt, bias, seed):
+    """The same draw at the sizes where the dispatcher's M- and K-dependent rules live (rows per workgroup, band counts, the LDS
+    fallback beyond K = 16384, up to 0.65 G weights): EVERY row against the float64 product formed on the device by the pure-torch
+    oracle, that evaluation tied to the C oracle on 16 sampled rows (first and last included)."""
+    from oracle import torch_cpu
+
+    K = kc * 32
+    bs = 64 if K % 64 == 0 else 32
+    g = torch.Generator(device=dev()).manual_seed(seed)
+    packed_d = torch.randint(0, 256, (M * K // 2,), dtype=torch.uint8, device=dev(), generator=g)
+    absmax_d = torch.rand(M * K // bs, device=dev(), generator=g) * 0.05 + 0.005
+    rng = np.random.default_rng(seed)
+    x_t = torch_values(rng.standard_normal(K), dt)
+    b_t = torch_values(rng.standard_normal(M) * 0.1, dt) if bias else None
+    y = hipabi.gemv(x_t, packed_d, absmax_d, M, K, bs, bias=b_t)
+    if bias:
+        plain = hipabi.gemv(x_t, packed_d, absmax_d, M, K, bs)
+        assert torch.equal(y, plain + b_t)
+        y = plain
+    table_d = torch_cpu.code_table("codebook").to(dev())
+    x64 = x_t.double()
+
+    def product(xv, magnitudes):  # float64 x @ W^T (or |x| @ |W|^T) over row chunks of <= 32 Mi weights
+        out = torch.empty(M, dtype=torch.float64, device=dev())
+        step = max(1, (1 << 25) // K)
+        for r0 in range(0, M, step):
+            r1 = min(M, r0 + step)
+            p = packed_d[r0 * K // 2:r1 * K // 2]
+            w = torch_cpu.dequantize(p & 0x77 if magnitudes else p, absmax_d[r0 * K // bs:r1 * K // bs], r1 - r0, K, bs, torch.float32, table_d)
+            out[r0:r1] = w.double() @ xv
+        return out
+
+    exact_d, scale_d = product(x64, False), product(x64.abs(), True)
+    rows = np.unique(np.concatenate([[0, M - 1], rng.integers(0, M, 14)]))
+    p_rows = packed_d.view(M, K // 2)[rows].cpu().numpy().reshape(-1)
+    a_rows = absmax_d.view(M, K // bs)[rows].cpu().numpy().reshape(-1)
+    want = c_oracle.gemv_f64(x64.cpu().numpy(), p_rows, a_rows, len(rows), K, bs)
+    assert np.allclose(exact_d[torch.from_numpy(rows).to(dev())].cpu().numpy(), want, rtol=1e-11, atol=1e-13)
+    half_ulp = {torch.bfloat16: 2.0**-8, torch.float16: 2.0**-11, torch.float32: 0.0}[dt]
+    tol = half_ulp * 1.01 * exact_d.abs() + 1e-5 * scale_d + 1e-30
+    err = (y.double() - exact_d).abs()
+    assert int((err > tol).sum().item()) == 0, (M, K, dt, float((err / tol).max().item()))
