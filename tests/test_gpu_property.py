@@ -98,3 +98,55 @@ def test_gemv_any_large_shape(M, kc, dt, bias, seed):
     tol = half_ulp * 1.01 * exact_d.abs() + 1e-5 * scale_d + 1e-30
     err = (y.double() - exact_d).abs()
     assert int((err > tol).sum().item()) == 0, (M, K, dt, float((err / tol).max().item()))
+
+
+@settings(max_examples=120, **COMMON)
+@given(B=st.integers(1, 128), M=st.integers(1, 40000), kc=st.integers(1, 256), dt=st.sampled_from([torch.bfloat16, torch.float16]),
+       bias=st.booleans(), seed=st.integers(0, 2**31))
+def test_small_batch_any_large_shape(B, M, kc, dt, bias, seed):
+    """fp4_hip_gemm_small over the whole range its dispatcher decides on - 1..128 activation rows, up to 40 000 weight rows, K any multiple
+    of 64 up to 16 384 (matrix-core one-shot / persistent, VALU, one-pass wide kernels with 1..4 column tiles, the 16-row splits): either
+    the shape is refused with a reason (UNSUPPORTED: the caller takes dequant + GEMM) or EVERY output element meets the GEMV's bar against
+    the float64 product formed on the device by the pure-torch oracle (tied to the C oracle on sampled weight rows)."""
+    from oracle import torch_cpu
+
+    K, bs = kc * 64, 64
+    g = torch.Generator(device=dev()).manual_seed(seed)
+    packed_d = torch.randint(0, 256, (M * K // 2,), dtype=torch.uint8, device=dev(), generator=g)
+    absmax_d = torch.rand(M * K // bs, device=dev(), generator=g) * 0.05 + 0.005
+    rng = np.random.default_rng(seed)
+    x_t = torch_values(rng.standard_normal((B, K)), dt)
+    b_t = torch_values(rng.standard_normal(M) * 0.1, dt) if bias else None
+    rc, y = hipabi.gemm_small(x_t, packed_d, absmax_d, M, K, bs, bias=b_t, expect_ok=None)
+    assert rc in (hipabi.OK, hipabi.ERR_UNSUPPORTED), (rc, hipabi.last_error())
+    if rc != hipabi.OK:
+        assert "not covered" in hipabi.last_error() or "dtype" in hipabi.last_error(), hipabi.last_error()
+        return
+    table_d = torch_cpu.code_table("codebook").to(dev())
+    x64 = x_t.double()
+    bias64 = b_t.double() if bias else torch.zeros(M, dtype=torch.float64, device=dev())
+    exact = torch.empty(B, M, dtype=torch.float64, device=dev())
+    scale = torch.empty(B, M, dtype=torch.float64, device=dev())
+    step = max(1, (1 << 24) // K)
+    for r0 in range(0, M, step):
+        r1 = min(M, r0 + step)
+        p, a = packed_d[r0 * K // 2:r1 * K // 2], absmax_d[r0 * K // bs:r1 * K // bs]
+        w = torch_cpu.dequantize(p, a, r1 - r0, K, bs, torch.float32, table_d).double()
+        exact[:, r0:r1] = x64 @ w.t() + bias64[r0:r1]
+        scale[:, r0:r1] = x64.abs() @ w.abs().t() + bias64[r0:r1].abs()
+    rows = np.unique(np.concatenate([[0, M - 1], rng.integers(0, M, 6)]))
+    p_rows = packed_d.view(M, K // 2)[rows].cpu().numpy().reshape(-1)
+    a_rows = absmax_d.view(M, K // bs)[rows].cpu().numpy().reshape(-1)
+    want = c_oracle.gemv_f64(x64[B - 1].cpu().numpy(), p_rows, a_rows, len(rows), K, bs) + bias64[torch.from_numpy(rows).to(dev())].cpu().numpy()
+    assert np.allclose(exact[B - 1, torch.from_numpy(rows).to(dev())].cpu().numpy(), want, rtol=1e-11, atol=1e-13)
+    half_ulp = {torch.bfloat16: 2.0**-8, torch.float16: 2.0**-11}[dt]
+    tol = half_ulp * 1.01 * exact.abs() + 1e-5 * scale + 1e-30
+    err = (y.double() - exact).abs()
+    assert int((err > tol).sum().item()) == 0, (B, M, K, dt, bias, float((err / tol).max().item()))
+    # the same call with the scratch buffer the library asks for (what the torch ops do): 33..64 rows on short weights with long rows then
+    # run as split-K over workgroups + an ordered reducing launch - a different summation order, the same bar
+    y_ws, asked = hipabi.gemm_small_ws(x_t, packed_d, absmax_d, M, K, bs, bias=b_t)
+    err = (y_ws.double() - exact).abs()
+    assert int((err > tol).sum().item()) == 0, ("ws", asked, B, M, K, dt, bias, float((err / tol).max().item()))
+    if asked == 0:
+        assert torch.equal(y_ws, y)
