@@ -150,3 +150,19 @@ def test_small_batch_any_large_shape(B, M, kc, dt, bias, seed):
     assert int((err > tol).sum().item()) == 0, ("ws", asked, B, M, K, dt, bias, float((err / tol).max().item()))
     if asked == 0:
         assert torch.equal(y_ws, y)
+    # the fused epilogues on whatever kernel the dispatcher picked: residual = one more rounded add on top of the plain result (bit-exact);
+    # gate|up pairs = torch's own silu(g) * u on the plain result's rows (same device exp: <= 1 ulp, >= 99.8 % identical)
+    res = torch_values(rng.standard_normal((B, M)), dt)
+    fused = hipabi.gemm_small_fused(x_t, packed_d, absmax_d, M, K, bs, bias=b_t, residual=res)
+    assert torch.equal(fused, (y.float() + res.float()).to(dt))
+    if M % 2 == 0:
+        rc2 = hipabi.gemm_small_fused(x_t, packed_d, absmax_d, M, K, bs, bias=b_t, epilogue=hipabi.EPILOGUE_SILU_MUL_PAIRS, expect_ok=False)
+        assert rc2 in (hipabi.OK, hipabi.ERR_UNSUPPORTED), (rc2, hipabi.last_error())
+        if rc2 == hipabi.OK:
+            gu = hipabi.gemm_small_fused(x_t, packed_d, absmax_d, M, K, bs, bias=b_t, epilogue=hipabi.EPILOGUE_SILU_MUL_PAIRS)
+            ref = torch.nn.functional.silu(y[:, 0::2]) * y[:, 1::2]
+            a, b = gu.view(torch.int16).int() & 0xFFFF, ref.contiguous().view(torch.int16).int() & 0xFFFF
+            a = torch.where((a & 0x8000) != 0, 0x8000 - a, a)
+            b = torch.where((b & 0x8000) != 0, 0x8000 - b, b)
+            d = (a - b).abs()
+            assert int(d.max().item()) <= 1 and float((d == 0).float().mean().item()) >= 0.998, (B, M, K, dt, int(d.max().item()))
