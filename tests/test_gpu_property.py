@@ -98,6 +98,13 @@ def test_gemv_any_large_shape(M, kc, dt, bias, seed):
     tol = half_ulp * 1.01 * exact_d.abs() + 1e-5 * scale_d + 1e-30
     err = (y.double() - exact_d).abs()
     assert int((err > tol).sum().item()) == 0, (M, K, dt, float((err / tol).max().item()))
+    # the residual epilogue on whichever geometry was picked: one more rounded add on top of the plain result, bit for bit
+    res = torch_values(rng.standard_normal(M), dt)
+    fused = hipabi.gemv_fused(x_t, packed_d, absmax_d, M, K, bs, None, res)
+    assert torch.equal(fused, y + res if dt == torch.float32 else (y.float() + res.float()).to(dt))
+    part = hipabi.gemv_partial(x_t, packed_d, absmax_d, M, K, bs) if dt != torch.float32 else None
+    if part is not None:  # the K-split building block: the raw f32 accumulator, same sum
+        assert int(((part.double() - exact_d).abs() > 1e-5 * scale_d + 1e-30).sum().item()) == 0
 
 
 @settings(max_examples=120, **COMMON)
