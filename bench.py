@@ -624,6 +624,20 @@ def box_stream_leg(packed, outs):
         time_replays(rp, 3, R)
         us = time_replays(rp, 7, R)[0]
         out[name] = round(probe.fp4_probe_bytes(mode, n) / us / 1e3, 1)
+    # ... and a bare read of exactly the GEMV's bytes per launch (9 453 568 B = 577 probe tiles), same rotation: the batch-1 GEMV's
+    # per-launch figure is launch + first byte + stream, and this is what that costs on this box with no arithmetic and no x at all
+    n_gv = gemv_bytes(M, K, BLOCKSIZE, 2)
+    if n_gv % 16384 == 0 and n_gv <= n:
+        def run_gv():
+            s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+            for i in range(R):
+                rc = probe.fp4_probe_stream(1, outs[(i + R // 2) % R].data_ptr(), outs[i].data_ptr(), n_gv, s)
+                if rc != 0:
+                    raise RuntimeError(f"fp4_probe_stream(read, {n_gv} B) failed with code {rc}")
+
+        rp = capture(run_gv)
+        time_replays(rp, 3, R)
+        out["read_only_gemv_bytes_us"] = round(time_replays(rp, 7, R)[0], 3)
     return out
 
 
@@ -1106,6 +1120,11 @@ def main():
                 return round((r_ + w_) / (w_ / rates["write_only"] + r_ / rates["read_only"]), 1)
 
             rf = line["roofline"]
+            if "read_only_gemv_bytes_us" in bs_:  # same run: a bare read of the GEMV's bytes per launch vs the GEMV
+                bs_ = dict(bs_)
+                bare = bs_.pop("read_only_gemv_bytes_us")
+                line["roofline_gemv"]["box_bare_read_same_bytes_us"] = bare
+                line["roofline_gemv"]["frac_of_box_bare_read_per_launch"] = round(bare / line["roofline_gemv"]["avg_launch_us"], 4)
             rf["box_stream_gbps"] = bs_
             rf["box_serial_rw_bound_gbps"] = rw_bound(bs_)
             rf["frac_of_box_stream"] = round(rf["achieved"] / rf["box_serial_rw_bound_gbps"], 4)

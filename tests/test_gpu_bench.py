@@ -41,6 +41,8 @@ def test_single_gpu_line_schema():
     assert abs(r["frac_of_box_stream"] - r["achieved"] / r["box_serial_rw_bound_gbps"]) < 1e-3 and 0.5 < r["frac_of_box_stream"] < 1.5, r
     assert min(bs["write_only"], bs["read_only"]) <= r["box_serial_rw_bound_gbps"] <= max(bs["write_only"], bs["read_only"])
     assert set(r["box_stream_stack_of_R_gbps"]) == set(bs) and 0.5 < r["steady_state_frac_of_box_stream"] < 1.5, r
+    gv = rec["roofline_gemv"]  # the GEMV per launch next to a bare read of the same bytes, same run
+    assert 1.0 < gv["box_bare_read_same_bytes_us"] < gv["avg_launch_us"] * 1.5 and 0.3 < gv["frac_of_box_bare_read_per_launch"] < 1.5, gv
 
 
 def test_the_stream_probe_moves_the_bytes_it_claims():

@@ -55,6 +55,21 @@ __global__ __launch_bounds__(THREADS) void stream_floor(const u32x4 *__restrict_
     if ((threadIdx.x & 63) == 0) out[(blockIdx.x * THREADS + threadIdx.x) >> 6] = acc;
 }
 
+// floor 2 (round 4): the bare read with the best geometry found for this chip (tools/stream_probe.hip, mode 1): 256-thread workgroups, a
+// wave reads 4 KiB contiguous as four 1-KiB instructions, 16 B per lane, non-temporal; packed bytes AND scales as one byte stream
+__global__ __launch_bounds__(256) void stream_floor2(const u32x4 *__restrict__ W, const u32x4 *__restrict__ A, uint32_t *__restrict__ out,
+                                                     int w_tiles, int a_tiles) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool second = (int)blockIdx.x >= w_tiles;
+    if (second && (int)blockIdx.x - w_tiles >= a_tiles) return;
+    const u32x4 *src = (second ? A + int64_t(blockIdx.x - w_tiles) * 1024 : W + int64_t(blockIdx.x) * 1024) + wave * 256 + lane;
+    u32x4 v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = __builtin_nontemporal_load(src + j * 64);
+    u32x4 acc = v[0] ^ v[1] ^ v[2] ^ v[3];
+    if (acc.x == 0x12345u && acc.y == 0x6789u && acc.z == 0xabcdu) out[threadIdx.x] = acc.w;
+}
+
 __global__ void empty_kernel(uint32_t *out) {
     if (threadIdx.x == 0 && blockIdx.x == 0 && out == nullptr) out[0] = 1;
 }
@@ -161,6 +176,18 @@ int main(int argc, char **argv) {
                                absmax[w], scratch, nchunks);                                                          \
         }                                                                                                             \
     });
+    {   // floor 2: whole 16-KiB tiles of the packed bytes and of the scales (both are multiples of 16 KiB at the shapes this is run on)
+        const int w_tiles = (int)((n / 2) / 16384), a_tiles = (int)((n / 64 * 4) / 16384);
+        const double b2 = double(w_tiles + a_tiles) * 16384.0;
+        for (int cold = 1; cold >= 0; --cold)
+            T.run(cold ? "floor2 probe geometry (bare read of weights + scales) cold" : "floor2 probe geometry (bare read of weights + scales) hot", R * reps, b2, [&] {
+                for (int i = 0; i < R * reps; ++i) {
+                    const int w = cold ? i % R : 0;
+                    hipLaunchKernelGGL(stream_floor2, dim3(w_tiles + a_tiles), dim3(256), 0, T.s, (const u32x4 *)packed[w], (const u32x4 *)absmax[w],
+                                       scratch, w_tiles, a_tiles);
+                }
+            });
+    }
     if (!quick) {
         FLOOR(1, 256, false, true) FLOOR(2, 256, false, true) FLOOR(4, 256, false, true) FLOOR(8, 256, false, true)
         FLOOR(4, 256, true, true) FLOOR(2, 512, true, true) FLOOR(4, 512, true, true) FLOOR(2, 1024, true, true)
