@@ -57,16 +57,20 @@ __global__ __launch_bounds__(THREADS) void stream_floor(const u32x4 *__restrict_
 
 // floor 2 (round 4): the bare read with the best geometry found for this chip (tools/stream_probe.hip, mode 1): 256-thread workgroups, a
 // wave reads 4 KiB contiguous as four 1-KiB instructions, 16 B per lane, non-temporal; packed bytes AND scales as one byte stream
+// (LOADS 16-byte loads per lane: 4 = the probe's tile of 16 KiB per workgroup; 2 / 1 = 8 / 4 KiB tiles, i.e. twice / four times the workgroups)
+template <int LOADS>
 __global__ __launch_bounds__(256) void stream_floor2(const u32x4 *__restrict__ W, const u32x4 *__restrict__ A, uint32_t *__restrict__ out,
                                                      int w_tiles, int a_tiles) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool second = (int)blockIdx.x >= w_tiles;
     if (second && (int)blockIdx.x - w_tiles >= a_tiles) return;
-    const u32x4 *src = (second ? A + int64_t(blockIdx.x - w_tiles) * 1024 : W + int64_t(blockIdx.x) * 1024) + wave * 256 + lane;
-    u32x4 v[4];
+    const u32x4 *src = (second ? A + int64_t(blockIdx.x - w_tiles) * (256 * LOADS) : W + int64_t(blockIdx.x) * (256 * LOADS)) + wave * (64 * LOADS) + lane;
+    u32x4 v[LOADS];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] = __builtin_nontemporal_load(src + j * 64);
-    u32x4 acc = v[0] ^ v[1] ^ v[2] ^ v[3];
+    for (int j = 0; j < LOADS; ++j) v[j] = __builtin_nontemporal_load(src + j * 64);
+    u32x4 acc = v[0];
+#pragma unroll
+    for (int j = 1; j < LOADS; ++j) acc ^= v[j];
     if (acc.x == 0x12345u && acc.y == 0x6789u && acc.z == 0xabcdu) out[threadIdx.x] = acc.w;
 }
 
@@ -183,10 +187,20 @@ int main(int argc, char **argv) {
             T.run(cold ? "floor2 probe geometry (bare read of weights + scales) cold" : "floor2 probe geometry (bare read of weights + scales) hot", R * reps, b2, [&] {
                 for (int i = 0; i < R * reps; ++i) {
                     const int w = cold ? i % R : 0;
-                    hipLaunchKernelGGL(stream_floor2, dim3(w_tiles + a_tiles), dim3(256), 0, T.s, (const u32x4 *)packed[w], (const u32x4 *)absmax[w],
+                    hipLaunchKernelGGL(stream_floor2<4>, dim3(w_tiles + a_tiles), dim3(256), 0, T.s, (const u32x4 *)packed[w], (const u32x4 *)absmax[w],
                                        scratch, w_tiles, a_tiles);
                 }
             });
+        T.run("floor2 with 2 loads per lane (twice the workgroups) cold", R * reps, b2, [&] {
+            for (int i = 0; i < R * reps; ++i)
+                hipLaunchKernelGGL(stream_floor2<2>, dim3(2 * (w_tiles + a_tiles)), dim3(256), 0, T.s, (const u32x4 *)packed[i % R], (const u32x4 *)absmax[i % R],
+                                   scratch, 2 * w_tiles, 2 * a_tiles);
+        });
+        T.run("floor2 with 1 load per lane (four times the workgroups) cold", R * reps, b2, [&] {
+            for (int i = 0; i < R * reps; ++i)
+                hipLaunchKernelGGL(stream_floor2<1>, dim3(4 * (w_tiles + a_tiles)), dim3(256), 0, T.s, (const u32x4 *)packed[i % R], (const u32x4 *)absmax[i % R],
+                                   scratch, 4 * w_tiles, 4 * a_tiles);
+        });
     }
     if (!quick) {
         FLOOR(1, 256, false, true) FLOOR(2, 256, false, true) FLOOR(4, 256, false, true) FLOOR(8, 256, false, true)
