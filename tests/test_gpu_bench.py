@@ -153,3 +153,20 @@ def test_the_group_path_through_real_rccl_with_one_rank():
     c5 = rec["c5_llama3_8b_tp"]
     assert c5["backend"] == "nccl" and c5["oneshot_selfcheck"]["ok"] is True and "error" not in c5["dist"], c5
     assert c5["allreduces_per_token"] == 4 and "error" not in c5.get("oneshot", {}), c5
+
+
+def test_more_rccl_ranks_than_devices_fails_fast_with_a_reason():
+    """`python bench.py --gpus 2` with the real backend on a box with ONE GPU (RCCL cannot put two ranks on a device): every rank says what
+    is missing and the launcher returns non-zero well inside the deadline - no hang, no half-initialised process group, no result line."""
+    import time
+
+    import torch
+
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this box has two or more GPUs")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "FP4_BENCH_BACKEND")}
+    t0 = time.monotonic()
+    p = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--matrices", "8"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and time.monotonic() - t0 < 120, (p.returncode, p.stderr[-1500:])
+    assert "needs 2 visible GPUs" in p.stderr and p.stdout.strip() == "", (p.stdout[-500:], p.stderr[-1500:])
