@@ -23,9 +23,11 @@ stdout carries the ONE JSON line and nothing else (claim_stdout: RCCL's version 
 Environment switches (all optional; none changes the timed region):
   FP4_BENCH_BACKEND=gloo      N > 1 with the ranks SHARING devices and gloo standing in for RCCL (one-GPU rehearsal of the N > 1 path)
   FP4_BENCH_FORCE_GROUP=1     take the N > 1 code path with one rank (the only way through real RCCL on a one-GPU box)
+  FP4_BENCH_C3=0              skip the sanity-MLP leg (BASELINE config 3: the reference's published table, re-measured; N = 1)
   FP4_BENCH_C4=0 / FP4_BENCH_C4_LAYERS=n      skip / shorten the Mistral-7B decode leg (N = 1)
   FP4_BENCH_C5=0 / FP4_BENCH_C5_LAYERS=n      skip / shorten the Llama-3-8B tensor-parallel leg (N > 1)
   FP4_BENCH_C5_ONESHOT=0      leave the one-shot all-reduce out of that leg;  FP4_BENCH_C5_GRAPH=1  also capture the RCCL variant in a HIP graph
+  FP4_BENCH_QUANT_STACK=0     leave the quantiser's stack-of-R launch out (PMC passes: its persistent grid cannot be told from the per-matrix one)
   FP4_BENCH_CPU_THREADS=n     cap the host threads of the cpu_baseline leg (default: the cgroup's share, at most 64)
 """
 from __future__ import annotations
@@ -295,16 +297,23 @@ def _die_with_parent():
 
 def _forward_termination(proc):
     """A TERM / HUP / INT sent to the launching parent (a driver's time limit, say) ends the worker group too, then the parent leaves
-    with 128 + signal.  Returns a callable that puts the previous handlers back.  (Handlers can only be set from the main thread;
+    with 128 + signal (through SystemExit, so that every `finally` on the way runs).  Returns a callable that puts the previous handlers back.  (Handlers can only be set from the main thread;
     elsewhere _die_with_parent is the only line of defence.)"""
     import signal
 
     previous = {}
 
     def handler(signum, _frame):
+        # Nothing that waits in here: the main thread may be inside proc.wait() holding Popen's wait lock, and a handler that
+        # waited on the same process would spin through both grace periods.  Leave through the normal flow instead - SystemExit
+        # unwinds _wait_for_workers (whose `except BaseException` ends the worker group) and launch_workers' `finally`
+        # (handlers restored, the stage directory removed) - and the process exits with 128 + signal.
         print(f"bench.py: signal {signum} received: ending the worker group", file=sys.stderr, flush=True)
-        _kill_group(proc)
-        os._exit(128 + signum)
+        try:
+            os.killpg(proc.pid, signal.SIGTERM)  # start the workers' shutdown at once; _kill_group escalates if they linger
+        except (ProcessLookupError, PermissionError):
+            pass
+        raise SystemExit(128 + signum)
 
     for sig in (signal.SIGTERM, signal.SIGHUP, signal.SIGINT):
         try:
@@ -520,7 +529,8 @@ def c5_leg(dist, backend, rank, world, dev, barrier, tokens=16):
                 st = par.oneshot_comm(None).status()
                 out[ar]["timeouts"] = int(st[3])  # lanes that gave up waiting for a peer (must be 0 for the figure to count)
                 par.check_oneshot(None)  # raises (-> "error" below) if any reduction of the leg timed out: its outputs were NaN
-            out["allreduces_per_token"] = meta["allreduces_per_token"]
+            out["allreduces_per_token"] = meta["allreduces_per_token"]  # issued inside the K-split layers (a one-rank group included)
+            out["collective_ranks"] = meta["collective_ranks"]  # 1 = FP4_BENCH_FORCE_GROUP rehearsal: the calls run, no data crosses a link
             out["fp4_bytes_per_token_per_gpu"] = meta["fp4_bytes_per_token_per_gpu"]
             del token, h0
         except Exception as exc:
@@ -564,6 +574,19 @@ def fused_epilogue_leg(lib, dev):
         out[name.split("_")[0] + "_plain_gemv_same_weight"] = round(time_replays(capture(plain), 5, r)[0], 3)
         del packed, absmax
     return out
+
+
+def c3_leg(pkg):
+    """Outside the timed region: BASELINE config 3, the only speed table the reference itself publishes (README.md:100-159), re-measured
+    on this build and this box: TestModel(768, 2048, 4, 64), [1,768] / [2,768], fp32 / fp16 / bf16, dense vs FP4, eager and HIP-graph
+    replay, the README's own figures beside them and the FP4-calls / dense-nn.Linear / GELU split (tools/sanity_bench.py; bounded)."""
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import sanity_bench as sb
+
+    t0 = time.perf_counter()
+    table = sb.c3_table(pkg)
+    table["leg_seconds"] = round(time.perf_counter() - t0, 1)
+    return table
 
 
 def c4_leg(dev, tokens=24):
@@ -668,6 +691,24 @@ def box_stream_stack_leg(big_p, big_o):
     return out
 
 
+def box_yardsticks(rf, read_bytes, write_bytes, per_launch, stack):
+    """What this box would need to read `read_bytes` and write `write_bytes` back to back at its own bare stream rates (same run, same
+    buffers, tools/stream_probe.hip), next to what the kernel achieved: an ESTIMATE from the per-launch probes (their read rate is
+    launch-limited, so it is no ceiling - a kernel that overlaps its two directions beats it), one from the steady-state probes over
+    the stack of R, and `best_of_both` (the better rate per direction): the one figure of the three a kernel should not exceed."""
+    def serial(read_rate, write_rate):
+        return round((read_bytes + write_bytes) / (write_bytes / write_rate + read_bytes / read_rate), 1)
+
+    est = {"per_launch_probes": serial(per_launch["read_only"], per_launch["write_only"])}
+    if "write_only" in stack:
+        est["stack_probes"] = serial(stack["read_only"], stack["write_only"])
+        est["best_of_both"] = serial(max(per_launch["read_only"], stack["read_only"]), max(per_launch["write_only"], stack["write_only"]))
+    rf["box_serial_rw_estimate_gbps"] = est
+    rf["frac_of_box_serial_rw"] = {k: round(rf["achieved"] / v, 4) for k, v in est.items() if k != "stack_probes"}
+    if "steady_state_gbps" in rf and "stack_probes" in est:
+        rf["steady_state_frac_of_box_serial_rw"] = {k: round(rf["steady_state_gbps"] / est[k], 4) for k in ("stack_probes", "best_of_both")}
+
+
 def capture(fn):
     """Capture fn() into a HIP graph (after one eager run) and return a replay callable."""
     fn()
@@ -693,26 +734,32 @@ def time_replays(replay, reps, launches):
     return statistics.median(out), out
 
 
-def committed_traffic(prefix: str):
+def committed_traffic(prefix: str, profiles_dir: str | None = None, repo: str = REPO):
     """Per-launch HBM bytes of a kernel from the committed PMC profile (profiles/rNN_traffic*.json, produced by
     tools/pmc_traffic.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this very script): the
-    latest round's file, and within a round the one marked "final" if there is one."""
+    latest round's file, and within a round the one marked "final" if there is one.  Returns (bytes, source, stale, reason):
+    the profile records the SHA-256 of the sources it was taken from, and a figure whose kernel has been edited since
+    (or whose profile predates the digests) is kept but marked stale (tools/source_digest.py)."""
     import glob
     import re
+
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import source_digest
 
     def order(path):
         name = os.path.basename(path)
         m = re.match(r"r(\d+)_", name)
         return (int(m.group(1)) if m else -1, "final" in name, name)
 
-    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_traffic*.json")), key=order)
+    files = sorted(glob.glob(os.path.join(profiles_dir or os.path.join(repo, "profiles"), "r*_traffic*.json")), key=order)
     if not files:
-        return None, None
+        return None, None, None, None
     data = json.load(open(files[-1]))
     for name, rec in data.items():
         if name.startswith(prefix):
-            return rec["traffic_bytes"], f"{os.path.relpath(files[-1], REPO)}:{name}"
-    return None, None
+            is_stale, why = source_digest.stale(data.get("_source_sha256"), name, repo)
+            return rec["traffic_bytes"], f"{os.path.relpath(files[-1], repo)}:{name}", is_stale, why
+    return None, None, None, None
 
 
 def device_info(dev):
@@ -954,9 +1001,13 @@ def main():
                 },
             }
             for key, prefix in (("roofline", "dequant_tiles_kernel<2,"), ("roofline_gemv", "gemv16_regx_kernel<2,")):
-                traffic, src = committed_traffic(prefix)
+                traffic, src, is_stale, why = committed_traffic(prefix)
                 line[key]["traffic"] = traffic
                 line[key]["traffic_source"] = src
+                if traffic is not None:
+                    line[key]["traffic_stale"] = bool(is_stale)
+                    if is_stale:
+                        line[key]["traffic_stale_reason"] = why
             def spread(ms, launches):  # median and inter-quartile range over the timed steps, us per launch (rank 0)
                 us = sorted(v * 1e3 / launches for v in ms)
                 q = statistics.quantiles(us, n=4) if len(us) >= 4 else [us[0], us[len(us) // 2], us[-1]]
@@ -1054,6 +1105,16 @@ def main():
             time_replays(rp, 15, 4)
             us = time_replays(rp, 9, 4)[0]
             extra["dequant_stack_of_R_one_launch_gbps"] = round(R * dequant_bytes(M, K, BLOCKSIZE, 2) / us / 1e3, 1)
+            # the quantiser over the same stack (reads the bf16 values the stacked dequant just wrote; outputs go over the inputs' buffers)
+            # (FP4_BENCH_QUANT_STACK=0, set by the PMC passes of tools/collect_profiles.sh: the quantiser's grid is persistent - the
+            #  same for every size - so its counters could not be told apart from the per-matrix launches' by grid like the others')
+            if os.environ.get("FP4_BENCH_QUANT_STACK", "1") == "1":
+                big_qp, big_qa = torch.empty(R * n // 2, dtype=torch.uint8, device=dev), torch.empty(R * n // BLOCKSIZE, dtype=torch.float32, device=dev)
+                rp = capture(lambda: [lib.quantize(big_o, big_qp, big_qa, R * n) for _ in range(4)])
+                time_replays(rp, 15, 4)
+                us = time_replays(rp, 9, 4)[0]
+                extra["quantize_stack_of_R_one_launch_gbps"] = round(R * dequant_bytes(M, K, BLOCKSIZE, 2) / us / 1e3, 1)
+                del big_qp, big_qa
             rp = capture(lambda: [lib.gemv(x, big_p, big_a, big_y, R * M, K) for _ in range(12)])
             time_replays(rp, 20, 12)
             us = time_replays(rp, 9, 12)[0]
@@ -1092,6 +1153,13 @@ def main():
                 extra["fused_epilogue_us"] = fused_epilogue_leg(lib, dev)
             except Exception as exc:
                 extra["fused_epilogue_us"] = {"error": repr(exc)[:200]}
+            # BASELINE config 3 (driver-visible): the reference's own sanity-MLP speed table on this build, with its README figures beside it
+            if world == 1 and os.environ.get("FP4_BENCH_C3", "1") == "1":
+                try:
+                    extra["c3_sanity_mlp"] = c3_leg(lib.pkg)
+                except Exception as exc:
+                    extra["c3_sanity_mlp"] = {"error": repr(exc)[:300]}
+                torch.cuda.empty_cache()
             # BASELINE config 4 (driver-visible): batch-1 decode through every FP4 Linear of a Mistral-7B shaped model
             if world == 1 and os.environ.get("FP4_BENCH_C4", "1") == "1":
                 try:
@@ -1107,18 +1175,26 @@ def main():
             line["roofline"]["steady_state_frac"] = round(extra["dequant_stack_of_R_one_launch_gbps"] / HBM_PEAK_GBPS, 4)
             line["roofline_gemv"]["steady_state_gbps"] = extra["gemv_stack_of_R_one_launch_gbps"]
             line["roofline_gemv"]["steady_state_frac"] = round(extra["gemv_stack_of_R_one_launch_gbps"] / HBM_PEAK_GBPS, 4)
+        if "quantize_bf16_us" in extra:
+            # row f1's kernel (load-time, not on the decode path) priced like the other two: 33.6 MB read, 9.4 MB written per launch
+            q_b = dequant_bytes(M, K, BLOCKSIZE, 2)
+            q_gbps = q_b / extra["quantize_bf16_us"] / 1e3
+            line["roofline_quantize"] = {
+                "bound": "hbm", "kernel": "quantize_kernel<bf16> (fp4_hip_quantize_blockwise)", "achieved": round(q_gbps, 1), "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s", "frac": round(q_gbps / HBM_PEAK_GBPS, 4), "traffic": None, "bytes_per_launch": q_b,
+                "avg_launch_us": extra["quantize_bf16_us"],
+                "method": "HIP events around graph replays of R back-to-back launches, HBM-cold rotation over the R bf16 weights (outside the timed region)",
+            }
+            traffic, src, is_stale, why = committed_traffic("quantize_")
+            if traffic is not None:
+                line["roofline_quantize"].update({"traffic": traffic, "traffic_source": src, "traffic_stale": bool(is_stale)})
+                if is_stale:
+                    line["roofline_quantize"]["traffic_stale_reason"] = why
+            if "quantize_stack_of_R_one_launch_gbps" in extra:
+                line["roofline_quantize"]["steady_state_gbps"] = extra["quantize_stack_of_R_one_launch_gbps"]
+                line["roofline_quantize"]["steady_state_frac"] = round(extra["quantize_stack_of_R_one_launch_gbps"] / HBM_PEAK_GBPS, 4)
         bs_, st_ = extra.get("box_stream_gbps", {}), extra.get("box_stream_stack_of_R_gbps", {})
         if "write_only" in bs_:
-            # Same run, same buffers, same launch structure, no arithmetic: what this box streams with the kernel's access geometry.
-            # The bare 1:4 mixes turn out SLOWER than the dequant kernel itself (they interleave reads and writes; the kernel's
-            # chip-wide "all loads, barrier, all stores" phases do not), so they are no ceiling; the yardstick that means something is
-            # the time this box needs to WRITE the kernel's output at its best write-only rate plus to READ its input at its best
-            # read-only rate, back to back (`box_serial_rw_bound_gbps`) - HBM is half-duplex, a 78 %-write stream cannot beat that by much.
-            r_, w_ = M * K // 2 + 4 * (M * K // BLOCKSIZE), M * K * 2
-
-            def rw_bound(rates):
-                return round((r_ + w_) / (w_ / rates["write_only"] + r_ / rates["read_only"]), 1)
-
             rf = line["roofline"]
             if "read_only_gemv_bytes_us" in bs_:  # same run: a bare read of the GEMV's bytes per launch vs the GEMV
                 bs_ = dict(bs_)
@@ -1126,18 +1202,20 @@ def main():
                 line["roofline_gemv"]["box_bare_read_same_bytes_us"] = bare
                 line["roofline_gemv"]["frac_of_box_bare_read_per_launch"] = round(bare / line["roofline_gemv"]["avg_launch_us"], 4)
             rf["box_stream_gbps"] = bs_
-            rf["box_serial_rw_bound_gbps"] = rw_bound(bs_)
-            rf["frac_of_box_stream"] = round(rf["achieved"] / rf["box_serial_rw_bound_gbps"], 4)
-            if "write_only" in st_ and "steady_state_gbps" in rf:
+            if "write_only" in st_:
                 rf["box_stream_stack_of_R_gbps"] = st_
-                rf["box_serial_rw_bound_stack_of_R_gbps"] = rw_bound(st_)
-                rf["steady_state_frac_of_box_stream"] = round(rf["steady_state_gbps"] / rf["box_serial_rw_bound_stack_of_R_gbps"], 4)
                 if "steady_state_gbps" in line["roofline_gemv"]:
                     line["roofline_gemv"]["steady_state_frac_of_box_read_stream"] = round(line["roofline_gemv"]["steady_state_gbps"] / st_["read_only"], 4)
+            box_yardsticks(rf, M * K // 2 + 4 * (M * K // BLOCKSIZE), M * K * 2, bs_, st_)
+            if "roofline_quantize" in line:  # reads the bf16 weight, writes the packed bytes + scales
+                box_yardsticks(line["roofline_quantize"], M * K * 2, M * K // 2 + 4 * (M * K // BLOCKSIZE), bs_, st_)
             rf["box_stream_note"] = ("tools/stream_probe.hip: the dequant kernel's access geometry without arithmetic (write only, read only, copy, a bare "
                                      "1-read : 4-write mix without and with the kernel's loads / barrier / stores phases), per 32 MiB launch like the headline "
-                                     "and as one launch over the stack of R; box_serial_rw_bound = bytes / (output bytes / write_only + input bytes / read_only); "
-                                     "frac_of_box_stream = achieved / that bound; `frac` stays against the 8 TB/s spec")
+                                     "and as one launch over the stack of R.  box_serial_rw_estimate_gbps = bytes / (bytes written / write_only + bytes read / "
+                                     "read_only) - reading and writing back to back at the box's bare rates - from the per-launch probes, from the stack "
+                                     "probes, and from the better of the two per direction (`best_of_both`: the only one of the three that is a ceiling; the "
+                                     "per-launch read probe is launch-limited, so a kernel that overlaps its reads with its writes can exceed that estimate). "
+                                     "`frac` stays against the 8 TB/s spec")
         if "dequant_plus_hipblaslt_gemv_us" in extra:
             line["fused_gemv_speedup_vs_dequant_hipblaslt"] = round(extra["dequant_plus_hipblaslt_gemv_us"] / gv_us, 2)
         if world == 1 and not args.no_cpu:

@@ -51,7 +51,7 @@ enum fp4_status {
     FP4_OK = 0,
     FP4_ERR_INVALID_ARGUMENT = 1, /* null pointer, negative size, unknown enum */
     FP4_ERR_UNSUPPORTED = 2,      /* shape/blocksize the kernels do not cover */
-    FP4_ERR_LAUNCH = 3            /* hipGetLastError() != hipSuccess after the launch */
+    FP4_ERR_LAUNCH = 3            /* the HIP runtime failed: hipGetLastError() != hipSuccess after a launch, or a memset / sync of a host-side helper */
 };
 
 FP4_HIP_API int fp4_hip_abi_version(void);
@@ -186,6 +186,11 @@ FP4_HIP_API int fp4_hip_gemv_partial(const void *x, const uint8_t *packed, const
  * lanes timed out} to the host (synchronous) so the caller can raise.  The status word is sticky (first time-out wins) until
  * fp4_hip_comm_clear_status zeroes it and the lane count (synchronous; the epoch is kept, the call sequence continues), so that a
  * transient time-out is reported once and later checks speak about later calls.
+ * Limit of that recovery: slots are double-buffered by call parity, so a rank that gave up on call n and carries on rewrites the slot of
+ * call n at call n + 2.  A peer that lags by LESS than one call still finds its data; one that lags further meets a newer epoch in
+ * the slot, times out in turn and writes NaN (never a wrong finite value).  Only the rank that timed out sees a status word - its peer
+ * may hold a valid result for the same call - so the decision to go on must be taken by the whole group: reduce the status words
+ * (MAX) over the ranks at the sync point and treat a non-zero result as a failure on every rank (OneShotAllReduce.check_collective).
  */
 FP4_HIP_API int64_t fp4_hip_comm_bytes(int world, int64_t capacity);
 FP4_HIP_API int fp4_hip_comm_alloc(int64_t bytes, void **ptr, uint8_t handle_out[64], int *kind_out);

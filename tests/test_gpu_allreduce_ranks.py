@@ -166,6 +166,21 @@ def _ipc_worker(rank, world, port, q):
                 res["timeout"] = str(exc)
             res["timeout_nan"] = bool(torch.isnan(y.float()).all().item())
         dist.barrier()
+        # ... and the group's view of the same situation: the rank that stayed away has no time-out of its own (a local check()
+        # would pass there while its peers raise), check_collective() raises on EVERY rank and names the ranks that gave up
+        lonely2 = comm_mod.OneShotAllReduce(None, capacity=1024, timeout_us=200_000)
+        if rank != world - 1:
+            lonely2.reduce(torch.ones(1024, device=dev), torch.bfloat16)
+        else:
+            lonely2.check()  # the local view of the absent rank: nothing to report
+        try:
+            lonely2.check_collective()
+            res["collective"] = "no error raised"
+        except RuntimeError as exc:
+            res["collective"] = str(exc)
+        lonely2.check_collective()  # cleared on the ranks that had timed out: the next collective check passes everywhere
+        dist.barrier()
+        lonely2.close()
         lonely.close()
         comm.close()
         q.put(res)
@@ -197,6 +212,9 @@ def test_world_4_one_process_per_rank_ipc_slots():
         assert r["layer_order_matters_torch.float32"]
         if r["rank"] != world - 1:
             assert f"timed out waiting for rank {world - 1}" in r["timeout"] and r["timeout_nan"], r
+        # the collective check raised on every rank - the absent one included - naming each rank that gave up
+        assert all(f"rank {k} (waiting for rank {world - 1}" in r["collective"] for k in range(world - 1)), r["collective"]
+        assert f"this is rank {r['rank']}" in r["collective"], r["collective"]
 
 
 # ---- world 3 / 5 as streams of ONE process, world 8 as 4 processes x 2 streams ------------------------------------------

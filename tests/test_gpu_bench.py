@@ -38,9 +38,27 @@ def test_single_gpu_line_schema():
     # the same-run streaming ceiling of this box (a measured figure next to the spec peak)
     bs = r["box_stream_gbps"]
     assert set(bs) == {"write_only", "read_only", "copy", "dequant_mix_1r_4w", "dequant_mix_1r_4w_loads_barrier_stores"} and all(1000 < v < 8000 for v in bs.values()), bs
-    assert abs(r["frac_of_box_stream"] - r["achieved"] / r["box_serial_rw_bound_gbps"]) < 1e-3 and 0.5 < r["frac_of_box_stream"] < 1.5, r
-    assert min(bs["write_only"], bs["read_only"]) <= r["box_serial_rw_bound_gbps"] <= max(bs["write_only"], bs["read_only"])
-    assert set(r["box_stream_stack_of_R_gbps"]) == set(bs) and 0.5 < r["steady_state_frac_of_box_stream"] < 1.5, r
+    est, fr = r["box_serial_rw_estimate_gbps"], r["frac_of_box_serial_rw"]
+    assert set(est) == {"per_launch_probes", "stack_probes", "best_of_both"} and set(r["box_stream_stack_of_R_gbps"]) == set(bs), est
+    assert min(bs["write_only"], bs["read_only"]) <= est["per_launch_probes"] <= max(bs["write_only"], bs["read_only"])
+    assert est["best_of_both"] >= max(est["per_launch_probes"], est["stack_probes"]) - 0.2
+    assert abs(fr["per_launch_probes"] - r["achieved"] / est["per_launch_probes"]) < 1e-3 and 0.5 < fr["per_launch_probes"] < 1.5, r
+    # `best_of_both` is the one yardstick meant as a ceiling (the better bare rate per direction, read and write back to back): a
+    # short 2-step run on a box with unsettled clocks gets 5 % of slack, no more
+    assert 0.5 < fr["best_of_both"] <= 1.05 and 0.5 < r["steady_state_frac_of_box_serial_rw"]["best_of_both"] <= 1.05, r
+    q = rec["roofline_quantize"]  # the quantiser (load-time kernel) against the same probes: reads the bf16 weight, writes 9.4 MB
+    assert q["bytes_per_launch"] == 42991616 and abs(q["frac"] - q["achieved"] / 8000.0) < 1e-3 and 0.2 < q["frac"] < 1.0, q
+    assert 0.4 < q["frac_of_box_serial_rw"]["best_of_both"] <= 1.05 and q["steady_state_gbps"] > 0.8 * q["achieved"], q
+    # BASELINE config 3: the reference's published table re-measured, README figures beside it, with the split
+    c3 = rec["c3_sanity_mlp"]
+    assert "error" not in c3 and len(c3["cells"]) == 6 and c3["leg_seconds"] < 60, c3
+    for cell in c3["cells"]:
+        assert cell["fp4_us"] > 0 and cell["fp4_graph_us"] < cell["fp4_us"] and set(cell["reference_readme_us"]) == {"pytorch", "bitsandbytes", "torch_bnb_fp4"}, cell
+        assert set(cell["split"]) >= {"three_fp4_layer_calls", "three_dense_nn_linear_calls", "four_gelus"}, cell
+        if cell["kind"] == "gemv":  # the fused GEMV path must not lose to the dense model it replaces, on the same box, in the same run
+            assert cell["fp4_us"] <= cell["dense_us"] * 1.02, cell
+        else:
+            assert cell["fp4_small_batch_fused_us"] <= cell["fp4_us"] * 1.02, cell
     gv = rec["roofline_gemv"]  # the GEMV per launch next to a bare read of the same bytes, same run
     assert 1.0 < gv["box_bare_read_same_bytes_us"] < gv["avg_launch_us"] * 1.5 and 0.3 < gv["frac_of_box_bare_read_per_launch"] < 1.5, gv
 
@@ -139,8 +157,11 @@ def test_the_group_path_through_real_rccl_with_one_rank():
     """RCCL refuses two ranks on one device, so a one-GPU box can only run the N > 1 code path through the REAL `nccl` backend with one
     rank: FP4_BENCH_FORCE_GROUP=1 makes bench.py take that path anyway - init_process_group("nccl", device_id=...), the `group` evidence
     (int64 sum / MIN, all_gather_object, an f32 sum, all on device tensors), the float64 all_gather of the per-rank totals, the barriers,
-    the K-split leg's eager all-reduces, the strong-split MAX reduce and the C5 leg on the tensor-parallel modules - every collective call
-    and dtype the 8-GPU run will issue, issued once through RCCL itself (what gloo rehearsals cannot show)."""
+    the K-split leg's eager all-reduces, the strong-split MAX reduce and the C5 leg on the tensor-parallel modules, whose K-split layers
+    are built with reduce_single_rank=True so that their in-layer all-reduces (`dist` row: dist.all_reduce through RCCL; `oneshot` row:
+    fp4_hip_allreduce_oneshot) really are issued, `allreduces_per_token` times per token, over the one-rank group - the collective calls
+    and dtypes of the 8-GPU run, issued through RCCL itself (what gloo rehearsals cannot show; what one rank cannot show is any data
+    crossing a link: `collective_ranks` is 1)."""
     rec = _run(["--steps", "2", "--warmup", "1", "--matrices", "8", "--no-cpu"],
                {"FP4_BENCH_FORCE_GROUP": "1", "FP4_BENCH_C5_LAYERS": "2", "FP4_BENCH_C4": "0"})
     g = rec["group"]
@@ -152,7 +173,8 @@ def test_the_group_path_through_real_rccl_with_one_rank():
     assert "error" not in rec["strong_scaling_row_split"] and rec["strong_scaling_row_split"]["rows_per_gpu"] == 4096
     c5 = rec["c5_llama3_8b_tp"]
     assert c5["backend"] == "nccl" and c5["oneshot_selfcheck"]["ok"] is True and "error" not in c5["dist"], c5
-    assert c5["allreduces_per_token"] == 4 and "error" not in c5.get("oneshot", {}), c5
+    assert c5["allreduces_per_token"] == 4 and c5["collective_ranks"] == 1 and "error" not in c5.get("oneshot", {}), c5
+    assert c5["oneshot"]["timeouts"] == 0 and c5["dist"]["eager_ms_per_token"] > 0, c5
 
 
 def test_more_rccl_ranks_than_devices_fails_fast_with_a_reason():

@@ -13,13 +13,13 @@ cd "$(dirname "$0")/.."
 export TMPDIR=/tmp FP4_BENCH_C4=${FP4_BENCH_C4:-1}
 python3 bench.py > "$out/bench.json" 2> "$out/bench.err"
 echo "bench: $(head -c 300 "$out/bench.json")"
-FP4_BENCH_C4=0 rocprofv3 --kernel-trace --stats -d "$out/trace" -o trace --output-format csv -- python3 bench.py --no-cpu --steps 5 --warmup 2 \
+FP4_BENCH_C4=0 FP4_BENCH_C3=0 FP4_BENCH_QUANT_STACK=0 rocprofv3 --kernel-trace --stats -d "$out/trace" -o trace --output-format csv -- python3 bench.py --no-cpu --steps 5 --warmup 2 \
     > "$out/profiled_run_line.json" 2> "$out/trace.err"
 python3 tools/trace_summary.py "$(find "$out/trace" -name '*kernel_trace.csv' | head -1)" "$out/trace_summary.json" \
     --bench-json "$out/profiled_run_line.json" --unprofiled-json "$out/bench.json" > "$out/trace_summary.txt"
 cp "$(find "$out/trace" -name '*kernel_stats.csv' | head -1)" "$out/kernel_stats.csv"
 for c in FETCH_SIZE WRITE_SIZE; do
-    FP4_BENCH_C4=0 rocprofv3 --kernel-trace --pmc $c -d "$out/pmc_$c" -o pmc --output-format csv -- python3 bench.py --no-cpu --steps 3 --warmup 1 \
+    FP4_BENCH_C4=0 FP4_BENCH_C3=0 FP4_BENCH_QUANT_STACK=0 rocprofv3 --kernel-trace --pmc $c -d "$out/pmc_$c" -o pmc --output-format csv -- python3 bench.py --no-cpu --steps 3 --warmup 1 \
         > "$out/pmc_$c.line" 2> "$out/pmc_$c.err"
 done
 python3 tools/pmc_traffic.py "$(find "$out/pmc_FETCH_SIZE" -name '*counter_collection.csv' | head -1)" \

@@ -77,7 +77,10 @@ def build_token_fn(cfg, dev, dtype, world=1, rank=0, group=None, fuse=False, epi
             return qd_of(packed, absmax, m, k).forward
         if kind == "col":
             return par.ColumnParallelFP4Linear(packed, absmax, (m, k), BS, group=group, gather_output=False)
-        return par.RowParallelFP4Linear(packed, absmax, (m, k), BS, group=group, input_is_parallel=True, allreduce=allreduce)
+        # a forced one-rank group (tensor_parallel=True at world 1) still issues its collectives, so that the rehearsal line's
+        # `allreduces_per_token` is what ran and not what would have run
+        return par.RowParallelFP4Linear(packed, absmax, (m, k), BS, group=group, input_is_parallel=True, allreduce=allreduce,
+                                        reduce_single_rank=(world == 1))
 
     layers = []
     for _ in range(L):
@@ -152,7 +155,8 @@ def build_token_fn(cfg, dev, dtype, world=1, rank=0, group=None, fuse=False, epi
     per_token_fp4 = L * (2 * fp4_bytes(H, H) + 2 * fp4_bytes(KV, H) + 2 * fp4_bytes(I, H) + fp4_bytes(H, I)) // world
     meta = dict(layers=L, fp4_bytes_per_token_per_gpu=per_token_fp4, lm_head_bytes=(V * H * 2 if lm_head else 0),
                 fp4_linear_calls_per_token=(4 if (fuse or epilogues) else 7) * L,
-                allreduces_per_token=(2 * L if tp else 0))
+                allreduces_per_token=(2 * L if tp else 0),  # issued by the K-split layers (also by a forced one-rank group: reduce_single_rank)
+                collective_ranks=world if tp else 0)
     return token, h0, meta
 
 

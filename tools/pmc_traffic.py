@@ -3,13 +3,19 @@
 per-launch HBM traffic for the FP4 kernels, with the gfx950 corrections of MI355X_MICROARCH.md (HBM section):
 FETCH_SIZE (KB) counts 64 B per 128-B request on streaming reads -> x2; WRITE_SIZE (KB) is exact.
 
+`_source_sha256` records the digest of every kernel source / header / build.py at collection time (tools/source_digest.py).
+
 usage: tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json>
 """
 import collections
 import csv
 import json
+import os
 import statistics
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from source_digest import file_digests  # noqa: E402
 
 
 def per_kernel(path, counter):
@@ -33,6 +39,8 @@ fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
 write = per_kernel(sys.argv[2], "WRITE_SIZE")
 out = {"_method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over `python bench.py --no-cpu "
                   "--steps 3 --warmup 1`; per-launch means; FETCH_SIZE doubled (gfx950 tallies 128-B requests at 64 B), WRITE_SIZE as is; KB = 1024 B"}
+# the sources these counters were taken from (the profile runs from the tree it sits in): bench.py marks the figure stale when they change
+out["_source_sha256"] = file_digests()
 for k in sorted(set(fetch) & set(write)):
     f_kb, nf = fetch[k]
     w_kb, nw = write[k]

@@ -197,11 +197,17 @@ extern "C" int fp4_hip_comm_status(const void *own_buffer, uint32_t out4[4]) {
 extern "C" int fp4_hip_comm_clear_status(void *own_buffer) {
     // status word + timed-out lane count (bytes 8..16 of the header); epoch and done counter stay: the call sequence goes on.
     // Synchronous, like fp4_hip_comm_status: to be called at a sync point, with no reduction of this rank in flight.
-    if (!own_buffer || hipDeviceSynchronize() != hipSuccess ||
-        hipMemset(static_cast<uint8_t *>(own_buffer) + 8, 0, 8) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
-        (void)hipGetLastError();
-        fp4::set_error("fp4_hip_comm_clear_status: cannot reset the header");
+    if (!own_buffer) {
+        fp4::set_error("fp4_hip_comm_clear_status: null buffer");
         return FP4_ERR_INVALID_ARGUMENT;
+    }
+    hipError_t err = hipDeviceSynchronize();
+    if (err == hipSuccess) err = hipMemset(static_cast<uint8_t *>(own_buffer) + 8, 0, 8);
+    if (err == hipSuccess) err = hipDeviceSynchronize();
+    if (err != hipSuccess) {  // a runtime failure, not a caller mistake
+        (void)hipGetLastError();
+        fp4::set_error("fp4_hip_comm_clear_status: cannot reset the header: %s", hipGetErrorString(err));
+        return FP4_ERR_LAUNCH;
     }
     return FP4_OK;
 }

@@ -138,13 +138,40 @@ class OneShotAllReduce:
         ext.comm_clear_status(self._own)
 
     def check(self) -> None:
-        """Raise if a reduction of this rank timed out SINCE THE LAST CHECK: the status is cleared before raising, so one transient
-        time-out is reported once and the communicator stays usable (all ranks still have to make the same calls in the same order)."""
+        """Raise if a reduction of THIS rank timed out since the last check; the status is cleared before raising, so one transient
+        time-out is reported once.  Local view only: the peer the rank gave up on may hold a valid result for the same call, so after
+        this raises on one rank the ranks' activations differ.  The communicator stays usable only while no rank lags by a whole call
+        (slots are double-buffered by call parity: a rank that carries on rewrites call n's slot at call n + 2, and a peer further
+        behind than that times out in turn and writes NaN - never a wrong finite value).  Where the decision to continue matters, use
+        :meth:`check_collective`, which makes it for the whole group."""
         epoch, _, status, lanes = self.status()
         if status:
             self.reset_status()
-            raise RuntimeError(f"OneShotAllReduce: rank {self.rank} timed out waiting for rank {(status & 0xFF) - 1} in call "
-                               f"{status >> 8} ({lanes} lanes gave up; {epoch} calls completed): outputs of that call are NaN")
+            raise RuntimeError(self._timeout_message(status, lanes, epoch))
+
+    def _timeout_message(self, status: int, lanes: int, epoch: int) -> str:
+        return (f"OneShotAllReduce: rank {self.rank} timed out waiting for rank {(status & 0xFF) - 1} in call "
+                f"{status >> 8} ({lanes} lanes gave up; {epoch} calls completed): outputs of that call are NaN")
+
+    def check_collective(self) -> None:
+        """The group's view, for the sync point of a decode loop (collective: every rank must call it; never inside graph capture).
+        Each rank's status word is gathered over the process group the communicator was built on; if ANY rank timed out since the
+        last check, every rank clears its status and raises the same error, naming the ranks that gave up - so no rank carries on
+        with a hidden state its peers do not share."""
+        epoch, _, status, lanes = self.status()
+        mine = torch.tensor([self.rank, status, lanes, epoch], dtype=torch.int64)
+        backend = dist.get_backend(self.group)
+        if backend == "nccl":
+            mine = mine.to(self.device)
+        got = [torch.empty_like(mine) for _ in range(self.world)]
+        dist.all_gather(got, mine, group=self.group)
+        bad = [tuple(int(v) for v in g.tolist()) for g in got if int(g[1]) != 0]
+        if bad:
+            if status:
+                self.reset_status()
+            raise RuntimeError("OneShotAllReduce: a reduction timed out on " + "; ".join(
+                f"rank {r} (waiting for rank {(st & 0xFF) - 1} in call {st >> 8}, {ln} lanes, {ep} calls completed)" for r, st, ln, ep in bad)
+                + f" - reported on every rank of the group (this is rank {self.rank}); outputs of those calls are NaN on the ranks named")
 
     def close(self) -> None:
         if getattr(self, "_own", None) is None:

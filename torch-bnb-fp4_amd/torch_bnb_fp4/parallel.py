@@ -112,6 +112,15 @@ def check_oneshot(group=None) -> None:
         comm.check()
 
 
+def check_oneshot_collective(group=None) -> None:
+    """:func:`check_oneshot` for the whole group (collective - every rank calls it at the same sync point): if a reduction timed out
+    on ANY rank since the last check, EVERY rank raises, so no rank carries on with activations its peers do not share
+    (:meth:`OneShotAllReduce.check_collective`).  No-op on every rank if the group has no communicator yet."""
+    comm = _COMMS.get((group, torch.cuda.current_device()))
+    if comm is not None:
+        comm.check_collective()
+
+
 def close_oneshot(group=None) -> None:
     """Release the group's one-shot communicator (collective: peers unmap each other's buffers after a barrier)."""
     comm = _COMMS.pop((group, torch.cuda.current_device()), None)
@@ -199,13 +208,17 @@ class RowParallelFP4Linear(nn.Module):
         return ok
 
     def __init__(self, packed, absmax, shape, blocksize: int = 64, bias: Optional[torch.Tensor] = None, group=None,
-                 input_is_parallel: bool = False, allreduce: str = "dist"):
+                 input_is_parallel: bool = False, allreduce: str = "dist", reduce_single_rank: bool = False):
         super().__init__()
         if allreduce not in ("dist", "oneshot"):
             raise ValueError(f"allreduce must be 'dist' or 'oneshot', got {allreduce!r}")
         self.group = group
         self.allreduce = allreduce
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        # A one-rank group needs no exchange and normally gets none.  reduce_single_rank=True issues the collective all the same (a sum
+        # over one rank is the identity): the only way to send this layer's real call sequence through RCCL / the one-shot kernel on a
+        # one-GPU box (bench.py FP4_BENCH_FORCE_GROUP=1).
+        self.reduces = self.world > 1 or bool(reduce_single_rank)
         p, a, local = shard_cols(packed, absmax, shape, blocksize, self.rank, self.world)
         self.quant_data = _quant_data(p, a, local, blocksize, None)
         self.bias = bias
@@ -247,7 +260,7 @@ class RowParallelFP4Linear(nn.Module):
                 w32 = ext.dequantize_fp4_codebook(qd.A, qd.absmax, qd.code, qd.M, qd.N, qd.blocksize, qd.numel, ScalarType.float32.value)
                 part = torch.nn.functional.linear(x2.float(), w32)
             part = part.view(*x.shape[:-1], self.out_features)
-        if self.world > 1 and self.allreduce == "oneshot" and part.is_cuda and part.numel() <= ONESHOT_CAPACITY:
+        if self.reduces and self.allreduce == "oneshot" and part.is_cuda and part.numel() <= ONESHOT_CAPACITY:
             # (latency-bound sizes only: decode and small batches; a prefill-sized partial goes through torch.distributed below)
             # one launch: publish into every peer's slots, gather, sum in rank order, round once, bias / residual on top
             comm = oneshot_comm(self.group)
@@ -255,7 +268,7 @@ class RowParallelFP4Linear(nn.Module):
             if bias is not None and part.numel() != self.out_features:
                 bias = bias.expand(part.shape).contiguous()
             return comm.reduce(part, x.dtype, bias, residual)
-        if self.world > 1:
+        if self.reduces:
             part = _all_reduce_sum(part, self.group)
         y = part.to(x.dtype)
         if self.bias is not None:
