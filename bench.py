@@ -573,6 +573,16 @@ def fused_epilogue_leg(lib, dev):
         out[name] = round(time_replays(capture(run), 5, r)[0], 3)
         out[name.split("_")[0] + "_plain_gemv_same_weight"] = round(time_replays(capture(plain), 5, r)[0], 3)
         del packed, absmax
+    # q|k|v row-concatenated (4096 + 1024 + 1024 rows): a plain GEMV, the fourth FP4 launch of a decoder layer
+    m, k = 6144, 4096
+    n = m * k
+    r = 32
+    gen = torch.Generator(device=dev).manual_seed(6)
+    packed = [torch.randint(0, 256, (n // 2,), dtype=torch.uint8, device=dev, generator=gen) for _ in range(r)]
+    absmax = [torch.rand(n // BLOCKSIZE, device=dev, generator=gen) * 0.02 + 0.002 for _ in range(r)]
+    x = torch.randn(k, device=dev).to(torch.bfloat16)
+    yq = torch.empty(m, dtype=torch.bfloat16, device=dev)
+    out["qkv_row_concat_plain_gemv_6144x4096"] = round(time_replays(capture(lambda: [lib.gemv(x, packed[i], absmax[i], yq, m, k) for i in range(r)]), 5, r)[0], 3)
     return out
 
 
@@ -589,9 +599,12 @@ def c3_leg(pkg):
     return table
 
 
-def c4_leg(dev, tokens=24):
+def c4_leg(dev, tokens=24, fused_us=None):
     """Outside the timed region: ms per token of batch-1 decode through 32 Mistral-7B shaped layers (+ dense lm_head), replayed
-    from a HIP graph, as separate launches, with q|k|v and gate|up row-concatenated, and with the fused epilogues."""
+    from a HIP graph: as separate launches, with q|k|v and gate|up row-concatenated, with the fused epilogues, and with the fused
+    epilogues over `lean` glue (ONE elementwise launch per layer in place of the six-launch attention stand-in) - plus the sum of the
+    FP4 kernels' own per-launch figures of this run (`fused_us`, HBM-cold) and the dense lm_head, so that the line says by itself how
+    much of a token is FP4 kernels at their per-launch floor and how much is stand-in glue and launch boundaries."""
     sys.path.insert(0, os.path.join(REPO, "tools"))
     import decode_bench as db
 
@@ -599,7 +612,8 @@ def c4_leg(dev, tokens=24):
     cfg["layers"] = int(os.environ.get("FP4_BENCH_C4_LAYERS", cfg["layers"]))
     out = {"model": "mistral7b shapes", "layers": cfg["layers"], "dtype": "bf16",
            "note": "synthetic FP4 bytes; attention replaced by identity; lm_head dense bf16; HIP-graph replay"}
-    for name, kw in (("separate_launches", {}), ("row_concat", {"fuse": True}), ("row_concat_plus_epilogues", {"epilogues": True})):
+    for name, kw in (("separate_launches", {}), ("row_concat", {"fuse": True}), ("row_concat_plus_epilogues", {"epilogues": True}),
+                     ("row_concat_plus_epilogues_lean_glue", {"epilogues": True, "lean_glue": True})):
         token, h0, meta = db.build_token_fn(cfg, dev, torch.bfloat16, **kw)
         t = db.time_tokens(token, h0, tokens, graph=True)
         out[name] = {"graph_ms_per_token": None if t["graph_s"] is None else round(t["graph_s"] * 1e3, 3),
@@ -607,6 +621,28 @@ def c4_leg(dev, tokens=24):
         out["hbm_floor_ms_per_token_at_8TBps"] = round((meta["fp4_bytes_per_token_per_gpu"] + meta["lm_head_bytes"]) / 8e12 * 1e3, 3)
         del token, h0
         torch.cuda.empty_cache()
+    out["row_concat_plus_epilogues_lean_glue"]["glue"] = "one elementwise launch per layer, no rescale (tools/decode_bench.py --lean-glue)"
+    keys = ("qkv_row_concat_plain_gemv_6144x4096", "o_plus_residual_4096x4096", "gate_up_silu_mul_28672x4096", "down_plus_residual_4096x14336")
+    if fused_us and all(k in fused_us for k in keys):
+        # the dense bf16 lm_head GEMV (262 MB: larger than the 256 MiB Infinity Cache, so every replay streams it from HBM)
+        head = torch.nn.Linear(cfg["hidden"], cfg["vocab"], bias=False, device=dev, dtype=torch.bfloat16)
+        h = torch.randn(1, cfg["hidden"], device=dev).to(torch.bfloat16)
+        with torch.inference_mode():
+            head_us = time_replays(capture(lambda: [head(h) for _ in range(4)]), 5, 4)[0]
+        del head
+        per_layer_us = sum(fused_us[k] for k in keys)
+        kernels_ms = (cfg["layers"] * per_layer_us + head_us) / 1e3
+        out["fp4_kernels_sum_ms"] = round(cfg["layers"] * per_layer_us / 1e3, 3)
+        out["lm_head_dense_gemv_ms"] = round(head_us / 1e3, 3)
+        out["decomposition"] = {
+            "per_layer_fp4_launch_us": {k: fused_us[k] for k in keys},
+            "fp4_kernels_plus_lm_head_ms": round(kernels_ms, 3),
+            "glue_and_boundaries_ms": {n_: round(out[n_]["graph_ms_per_token"] - kernels_ms, 3)
+                                       for n_ in ("row_concat_plus_epilogues", "row_concat_plus_epilogues_lean_glue") if out[n_]["graph_ms_per_token"]},
+            "note": "fp4_kernels_sum_ms = layers x the four per-launch figures of `fused_epilogue_us` (same run, HBM-cold, one kernel boundary each); "
+                    "what is left of a graph-replayed token is the attention stand-in's elementwise launches (six per layer by default, one with lean "
+                    "glue) and their boundaries - not FP4 work",
+        }
     return out
 
 
@@ -1163,7 +1199,7 @@ def main():
             # BASELINE config 4 (driver-visible): batch-1 decode through every FP4 Linear of a Mistral-7B shaped model
             if world == 1 and os.environ.get("FP4_BENCH_C4", "1") == "1":
                 try:
-                    extra["c4_mistral7b_decode"] = c4_leg(dev)
+                    extra["c4_mistral7b_decode"] = c4_leg(dev, fused_us=extra.get("fused_epilogue_us"))
                 except Exception as exc:
                     extra["c4_mistral7b_decode"] = {"error": repr(exc)[:300]}
 

@@ -217,7 +217,7 @@ FP4_HIP_API int fp4_hip_quantize_blockwise(const void *w, int w_dtype, uint8_t *
 /*
  * Tuning hook for benchmarks/sweeps: selects a kernel geometry by name
  * ("dequant", "gemv", "gemm_small", "gemm_wide" = rows per workgroup of the 17..64-row kernels (1 / 2 / 3 / 4 = 16 / 32 / 64 / 128, 5 = 16 with self-contained waves; 0 = off),
- * "quantize" = workgroups per CU of the persistent grid).  variant < 0 (quantize: 0) restores the built-in heuristic.
+ * "quantize": 1..999 = the persistent kernel with that many workgroups per CU, 1001 / 1002 / 1004 = the one-shot tiles kernel with 1 / 2 / 4 loads per lane).  variant < 0 (quantize: 0) restores the built-in heuristic.
  * Process-wide (relaxed atomics: safe to flip while other threads launch, each launch
  * reads it once); for sweeps and tests only, not part of the reference surface.
  */

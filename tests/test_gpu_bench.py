@@ -35,6 +35,11 @@ def test_single_gpu_line_schema():
     fe, c4 = rec["fused_epilogue_us"], rec["c4_mistral7b_decode"]
     assert "error" not in fe and fe["gate_up_silu_mul_28672x4096"] > 0 and "error" not in c4, (fe, c4)
     assert c4["row_concat_plus_epilogues"]["graph_ms_per_token"] < c4["separate_launches"]["graph_ms_per_token"]
+    # ... and its decomposition: FP4 kernels at their own per-launch figures + the dense lm_head, the rest being stand-in glue
+    dec = c4["decomposition"]
+    assert c4["row_concat_plus_epilogues_lean_glue"]["graph_ms_per_token"] <= c4["row_concat_plus_epilogues"]["graph_ms_per_token"] * 1.02, c4
+    assert abs(c4["fp4_kernels_sum_ms"] - c4["layers"] * sum(dec["per_layer_fp4_launch_us"].values()) / 1e3) < 2e-3, c4
+    assert 0 < c4["fp4_kernels_sum_ms"] < c4["row_concat_plus_epilogues"]["graph_ms_per_token"] and c4["lm_head_dense_gemv_ms"] > 0.02, c4
     # the same-run streaming ceiling of this box (a measured figure next to the spec peak)
     bs = r["box_stream_gbps"]
     assert set(bs) == {"write_only", "read_only", "copy", "dequant_mix_1r_4w", "dequant_mix_1r_4w_loads_barrier_stores"} and all(1000 < v < 8000 for v in bs.values()), bs

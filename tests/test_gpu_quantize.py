@@ -14,6 +14,20 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("bs", [32, 64, 128, 256, 512, 1024, 2048, 4096])
+@pytest.mark.parametrize("tiles", [3, 16])
+def test_quantize_whole_tiles_matches_oracle(dtype, bs, tiles):
+    """n a multiple of 8192: the one-shot tiles kernel where blocks fit a wave (bs <= 512), the persistent kernel otherwise, and the
+    persistent kernel forced - all bit-exact (zero blocks, a zero element, values at every magnitude)."""
+    n = 8192 * tiles
+    rng = np.random.default_rng(bs + tiles)
+    w = (rng.standard_normal(n) * 10.0 ** rng.uniform(-3, 3, n)).astype(np.float32)
+    w[bs : 2 * bs] = 0.0
+    w[5] = 0.0
+    _check(torch.from_numpy(w).to(dtype), bs)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("bs", [32, 64, 128, 256, 512, 1024, 2048, 4096])
 def test_quantize_matches_oracle(dtype, bs):
     n = 4096 * 37 + 8 * 5 + 3  # ragged: partial last block, partial last dword, odd n
     rng = np.random.default_rng(bs)
@@ -31,11 +45,17 @@ def test_quantize_matches_oracle(dtype, bs):
 
 
 def _check(w_t, bs):
-    packed, absmax = hipabi.quantize(w_t.to(dev()), bs)
+    """Every kernel against the oracle: the library's own choice (variant 0: by dtype and size, csrc/quantize_fp4.hip), the persistent
+    kernel forced (4 workgroups per CU) and the one-shot tiles kernel with 1 / 2 / 4 loads per lane (1001 / 1002 / 1004; it applies to
+    whole tiles with blocks of at most 512 elements and hands everything else to the persistent kernel)."""
     want_p, want_a = o.quantize_fp4(w_t.float().cpu().numpy().reshape(-1), bs)
-    np.testing.assert_array_equal(absmax.cpu().numpy(), want_a)  # NaN == NaN here
-    bad = np.flatnonzero(packed.cpu().numpy() != want_p)
-    assert bad.size == 0, (bad[:8], packed.cpu().numpy()[bad[:8]], want_p[bad[:8]])
+    for variant in (0, 4, 1001, 1002, 1004):
+        hipabi.set_variant("quantize", variant)
+        packed, absmax = hipabi.quantize(w_t.to(dev()), bs)
+        np.testing.assert_array_equal(absmax.cpu().numpy(), want_a)  # NaN == NaN here
+        bad = np.flatnonzero(packed.cpu().numpy() != want_p)
+        assert bad.size == 0, (variant, bad[:8], packed.cpu().numpy()[bad[:8]], want_p[bad[:8]])
+    hipabi.set_variant("quantize", 0)
 
 
 def test_quantize_threshold_neighbourhoods():

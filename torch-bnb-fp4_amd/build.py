@@ -150,11 +150,22 @@ def build_stream_probe(force: bool = False) -> str:
     return PROBE_LIB
 
 
-def build_all(force: bool = False, ext: bool = True):
+def build_all(force: bool = False, ext: bool = True, probe: bool = True):
+    """The product's two artefacts, then (probe=True: the test session, __graft_entry__.build(), this file run as a script) bench.py's
+    measuring stick.  The probe is not part of the product: packaging (setup.py) leaves it out, and a missing source or a failed
+    compile of it never fails a build - bench.py reports its figures as unavailable instead."""
     out = [build_hip_lib(force)]
     if ext:
         out.append(build_torch_ext(force))
-    out.append(build_stream_probe(force))
+    if probe:
+        if not os.path.exists(PROBE_SRC):
+            print(f"note: {os.path.relpath(PROBE_SRC, REPO)} is absent; bench.py will run without its box-stream figures", file=sys.stderr, flush=True)
+        else:
+            try:
+                out.append(build_stream_probe(force))
+            except (subprocess.CalledProcessError, OSError) as exc:
+                print(f"warning: the stream probe (bench-only) did not build: {exc}; bench.py will run without its box-stream figures",
+                      file=sys.stderr, flush=True)
     return out
 
 

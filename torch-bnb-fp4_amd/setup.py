@@ -21,7 +21,7 @@ sys.path.insert(0, HERE)
 def _build_native():
     import build as native  # build.py next to this file
 
-    native.build_all()
+    native.build_all(probe=False)  # the product only: tools/stream_probe.hip is bench.py's measuring stick, not shipped
     return native.EXT_LIB
 
 
