@@ -798,6 +798,18 @@ def committed_traffic(prefix: str, profiles_dir: str | None = None, repo: str = 
     return None, None, None, None
 
 
+def latest_profile(suffix: str) -> str:
+    """The newest round's committed profiles/rNN_<suffix> (by round number), as a path relative to the repository."""
+    import glob
+    import re
+
+    files = glob.glob(os.path.join(REPO, "profiles", f"r*_{suffix}"))
+    if not files:
+        return f"profiles/rNN_{suffix} (none committed)"
+    best = max(files, key=lambda f: int(re.match(r"r(\d+)_", os.path.basename(f)).group(1)))
+    return os.path.relpath(best, REPO)
+
+
 def device_info(dev):
     """What the box says it is (record the device next to the roofline it is priced against)."""
     try:
@@ -1028,7 +1040,7 @@ def main():
                     "bytes_per_launch": dq_b,
                     "avg_launch_us": round(dq_us, 3),
                     "method": "HIP events around each graph replay of R back-to-back launches on the launch stream; includes one kernel "
-                              "boundary per launch; rocprofv3 trace of this command: profiles/r04_bench_kernel_trace_summary.json (roofline_rows)",
+                              f"boundary per launch; rocprofv3 trace of this command: {latest_profile('bench_kernel_trace_summary.json')} (roofline_rows)",
                 },
                 "roofline_gemv": {
                     "bound": "hbm", "kernel": "gemv16_regx_kernel<bf16> (fp4_hip_gemv)", "achieved": round(gv_gbps_gpu, 1),

@@ -154,6 +154,13 @@ def measure_cell(pkg, dtype, kind):
             cell["fp4_small_batch_fused_us"], cell["fp4_small_batch_fused_graph_us"] = fused["eager_us"], fused["graph_us"]
             cell["split"]["three_fp4_layer_calls_small_batch_fused"] = _both(fp4_calls)
             pkg.set_small_batch_fused(model, False)
+        # the hardware-neutral comparison: FP4 relative to the dense model on the SAME box (ours measured here, the reference's from its README)
+        ref = cell["reference_readme_us"]
+        cell["fp4_over_dense"] = round(cell["fp4_us"] / cell["dense_us"], 3)
+        cell["fp4_graph_over_dense_graph"] = round(cell["fp4_graph_us"] / cell["dense_graph_us"], 3)
+        cell["reference_readme_fp4_over_dense"] = round(ref["torch_bnb_fp4"] / ref["pytorch"], 3)
+        if "fp4_small_batch_fused_us" in cell:
+            cell["fp4_small_batch_fused_over_dense"] = round(cell["fp4_small_batch_fused_us"] / cell["dense_us"], 3)
         sp = cell["split"]
         cell["split"]["sum_eager_us"] = round(sum(sp[k]["eager_us"] for k in ("three_fp4_layer_calls", "three_dense_nn_linear_calls", "four_gelus")), 2)
     del model
@@ -170,6 +177,12 @@ def c3_table(pkg):
                   "alone in the same run; bitsandbytes is not available on this platform",
         "cells": cells,
         "fp4_not_slower_than_dense_eager": {f"{c['dtype']}_{c['kind']}": bool(c["fp4_us"] <= c["dense_us"]) for c in cells},
+        "fp4_over_dense_vs_reference_readme": {f"{c['dtype']}_{c['kind']}": [c["fp4_over_dense"], c["reference_readme_fp4_over_dense"]] for c in cells},
+        "reading": "fp4_over_dense_vs_reference_readme = [FP4 / dense on this box, the same ratio from the reference's README].  GEMV rows: the fused "
+                   "GEMV beats the dense model it replaces (the README has its FP4 model ~1.19x SLOWER than dense).  GEMM rows take the reference's "
+                   "dispatch (dequantise, then the dense GEMM): one more launch per FP4 layer than the dense model on a forward that is host-bound - "
+                   "`split` shows every FP4 call costing an at::linear like dense's plus the dequant launch - so they sit somewhat above dense, as "
+                   "they do in the README (1.24-1.36x there); the opt-in fused small-batch kernels (fp16 / bf16) bring those rows below dense",
     }
 
 
@@ -190,12 +203,13 @@ def check(pkg, dtype):
 
 def render(table):
     lines = [f"{'dtype':9s}{'kind':6s}{'dense':>9s}{'fp4':>9s}{'fp4 graph':>11s}{'dense graph':>13s}{'fused(b2)':>11s}   README pytorch / bnb / torch-bnb-fp4   "
-             "split eager: 3 fp4 | 3 dense | 4 gelu"]
+             "split eager: 3 fp4 | 3 dense | 4 gelu   fp4/dense: here | README"]
     for c in table["cells"]:
         r, s = c["reference_readme_us"], c["split"]
         lines.append(f"{c['dtype']:9s}{c['kind']:6s}{c['dense_us']:9.2f}{c['fp4_us']:9.2f}{c['fp4_graph_us']:11.2f}{c['dense_graph_us']:13.2f}"
                      f"{c.get('fp4_small_batch_fused_us', float('nan')):11.2f}   {r['pytorch']:7.2f} /{r['bitsandbytes']:7.2f} /{r['torch_bnb_fp4']:7.2f}"
-                     f"            {s['three_fp4_layer_calls']['eager_us']:6.2f} | {s['three_dense_nn_linear_calls']['eager_us']:6.2f} | {s['four_gelus']['eager_us']:6.2f}")
+                     f"            {s['three_fp4_layer_calls']['eager_us']:6.2f} | {s['three_dense_nn_linear_calls']['eager_us']:6.2f} | {s['four_gelus']['eager_us']:6.2f}"
+                     f"        {c['fp4_over_dense']:5.2f} | {c['reference_readme_fp4_over_dense']:5.2f}")
     return "\n".join(lines)
 
 
