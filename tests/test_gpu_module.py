@@ -481,3 +481,53 @@ def test_set_small_batch_fused_switches_the_batch_path():
     assert torch.equal(again, ref)
     assert torch.allclose(fused.float(), ref.float(), rtol=2e-2, atol=2e-2)
 
+
+
+def test_the_readme_usage_snippets_run_as_written():
+    """The two usage snippets of the reference's README (README.md:169-196 and :213-238), with nothing changed but the package they
+    import from: a user of the reference who switches must find every name, keyword and call order they use.  Values are checked against
+    the float64 product of the dequantised weight (the batch path: dequant + dense GEMM, fp16)."""
+    from torch_bnb_fp4 import TorchFP4Linear, recursively_replace_with_fp4_linear, swap_linear_with_bnb_linear
+
+    torch.manual_seed(3)
+    # --- snippet 1 (README.md:169-196) ---
+    original_linear_layer = nn.Linear(in_features=512, out_features=1024, bias=True).to(device="cuda", dtype=torch.float16)
+    bias = original_linear_layer.bias.detach().clone()
+    original_linear_layer = swap_linear_with_bnb_linear(original_linear_layer, dtype=torch.float16).cuda()  # .cuda() quantises
+    quantized_linear_layer = TorchFP4Linear(original_linear_layer, use_codebook_dequant=True).to(device="cuda", dtype=torch.float16)
+    input_tensor = torch.randn(10, 512).to(device="cuda", dtype=torch.float16)
+    output = quantized_linear_layer(input_tensor)
+    assert output.dtype == torch.float16 and output.shape == (10, 1024)
+    qd = quantized_linear_layer.quant_data
+    w = o.dequantize_f32(qd.A.cpu().numpy().reshape(-1), qd.absmax.cpu().numpy(), 64, 1024 * 512, "codebook").reshape(1024, 512)
+    w16 = torch.from_numpy(w).half().double().numpy()  # the batch path rounds the dequantised weight to the activation dtype first
+    want = input_tensor.double().cpu().numpy() @ w16.T + bias.double().cpu().numpy()
+    got = output.double().cpu().numpy()
+    assert np.abs(got - want).max() <= 2.0**-10 * np.abs(want).max() + 2e-3, np.abs(got - want).max()
+    # the single-token call of the same layer takes the fused GEMV and agrees with the batch path's row
+    one = quantized_linear_layer(input_tensor[:1])
+    assert one.shape == (1, 1024) and (one.float() - output[:1].float()).abs().max().item() < 0.02
+
+    # --- snippet 2 (README.md:213-238): the HF model is replaced by a stand-in holding FP4 layers and an lm_head ---
+    DTYPE = torch.float16
+
+    class Stand(nn.Module):
+        def __init__(self):
+            super().__init__()
+            P = pkg()
+            self.layers = nn.ModuleList([P.swap_linear_with_bnb_linear(nn.Linear(256, 256), dtype=DTYPE) for _ in range(2)])
+            self.dense = nn.Linear(256, 256)  # not a bnb layer: only_replace_bnb_layers=True must leave it alone
+            self.lm_head = P.swap_linear_with_bnb_linear(nn.Linear(256, 1000), dtype=DTYPE)
+
+    model = Stand().to("cuda")
+    recursively_replace_with_fp4_linear(
+        model,
+        as_dtype=DTYPE,
+        use_codebook_dequant=True,
+        only_replace_bnb_layers=True,
+        ignore_layer_names=["lm_head"],
+    )  # in place, return value unused - as in the README
+    assert all(isinstance(l, TorchFP4Linear) for l in model.layers)
+    assert type(model.dense) is nn.Linear and not isinstance(model.lm_head, TorchFP4Linear)
+    h = torch.randn(1, 256, device="cuda", dtype=DTYPE)
+    assert model.layers[1](model.layers[0](h)).shape == (1, 256)
