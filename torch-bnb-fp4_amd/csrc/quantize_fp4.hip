@@ -6,10 +6,12 @@
 //   absmax = max|w| over the block;  x = w * (1/absmax) in f32;
 //   magnitude rank = #{t in thresholds : |x| > t};  code = rankmap[rank] | (x < 0 ? 8 : 0);
 //   even element -> high nibble.
-// 2-4 B read and 0.5625 B written per element; the ranking arithmetic is what has to be kept off the
-// critical path (see encode8).  Each lane owns 8 consecutive elements (one 16-byte load for 16-bit inputs) and emits
-// one packed dword, so loads and stores are both fully coalesced; the block maximum is a butterfly over
-// the bs/8 lanes that share a block (DPP up to 16 lanes, cross-wave through LDS only for blocksize > 512).
+// 2-4 B read and 0.5625 B written per element.  Each lane owns 8 consecutive elements (one 16-byte load for 16-bit inputs) and
+// emits one packed dword, so loads and stores are both fully coalesced; the block maximum is a butterfly over the bs/8 lanes
+// that share a block (DPP up to 16 lanes, cross-wave through LDS only for blocksize > 512); the ranking costs 5 vector
+// instructions per element (encode8_fast).  Two kernels share all of that and differ in memory structure only: the persistent
+// quantize_kernel (next tile's load in flight behind the tile being ranked) and the one-shot quantize_tiles_kernel (the dequant
+// kernel's geometry: every load of a lane up front); fp4_hip_quantize_blockwise picks by dtype and size from measurements.
 #include <algorithm>
 #include <atomic>
 
@@ -24,17 +26,18 @@ constexpr int kQThreads = 512;  // 4096 elements per workgroup = the largest sup
 // Ranking.  Thresholds = midpoints between neighbouring magnitudes of {0, 1/192, 1/6, 1/4, 1/3, 1/2, 2/3, 1}, strict '>'
 // (the published bitsandbytes rule, see oracle/fp4_oracle.py).  Done naively (seven float compares per element, ~70
 // instructions with the SGPR-mask round trips) the kernel is VALU-bound at a third of the HBM rate, so the rank comes
-// from a 71-entry table in LDS instead, exactly:
+// from a bucket table in LDS instead, exactly:
 //   * for non-negative floats the unsigned order of the BIT PATTERNS is the numeric order;
-//   * bucket = bits >> 20 (exponent + 3 mantissa bits); every threshold falls in a different bucket, so inside a bucket
+//   * bucket = bits 30..20 (exponent + 3 mantissa bits); every threshold falls in a different bucket, so inside a bucket
 //     the rank is `rank_lo`, plus one if the low 20 bits exceed that bucket's threshold;
-//   * the entry is (7 - rank_lo) << 28 | threshold_low20 (0xFFFFF if the bucket has none): subtracting the element's low
-//     20 bits borrows out of bit 28 exactly when they exceed the threshold, leaving r = 7 - rank in bits 30..28;
-//   * the LDS copy (fill_lut) covers EVERY bucket from 0 - everything below the first threshold's bucket is rank 0, 1.0 is the
-//     last bucket - and each entry has its own bucket number << 20 added, so that `entry - bits` needs no mask of the low 20 bits.
-// The sign of x goes into bit 31 with one v_bitop3, one v_alignbit pushes the nibble [sign r2 r1 r0] into the packed word
-// and three bitwise ops on the finished word turn all eight r's into codes (rank -> code is {0,1,6,7,4,5,2,3}, i.e.
-// code = [r2^r1, ~r1, ~r0]).  ~13 issue slots per element; rates: profiles/r01_f_exp_valu_int_rates.txt.
+//   * the constant table below holds, for the 71 buckets from the first threshold's to 1.0's, (7 - rank_lo) << 28 | threshold_low20
+//     (0xFFFFF if the bucket has none): subtracting the element's low 20 bits borrows out of bit 28 exactly when they exceed the
+//     threshold, leaving r = 7 - rank in bits 30..28;
+//   * the LDS copy (fill in the kernels) covers EVERY bucket from 0 - everything below the first threshold's bucket is rank 0 -
+//     and each entry has its own bucket number << 20 added, so that `entry - bits` needs no mask of the low 20 bits, no clamp of
+//     |x| and - see encode8_fast - not even a separate sign merge.
+// One v_alignbit pushes the nibble [sign r2 r1 r0] into the packed word and three bitwise ops on the finished word turn all
+// eight r's into codes (rank -> code is {0,1,6,7,4,5,2,3}, i.e. code = [r2^r1, ~r1, ~r0]).  Issue rates: profiles/r01_f_exp_valu_int_rates.txt.
 constexpr uint32_t kThresholdBits[7] = {
     __builtin_bit_cast(uint32_t, 0.00260417f), __builtin_bit_cast(uint32_t, 0.0859375f),
     __builtin_bit_cast(uint32_t, 0.20833333f), __builtin_bit_cast(uint32_t, 0.29166667f),
