@@ -17,7 +17,8 @@ KERNEL_SOURCES = {
     "quantize_": [os.path.join(CSRC, "quantize_fp4.hip")] + COMMON,
     # (longest prefix first: dict order is lookup order)
     "gemm16_wide": [os.path.join(CSRC, "gemm_wide_fp4.hip"), os.path.join(CSRC, "gemv_common.h")] + COMMON,
-    "gemm16_splitk": [os.path.join(CSRC, "gemm_splitk_fp4.hip"), os.path.join(CSRC, "gemv_common.h")] + COMMON,
+    "gemm16_xstat": [os.path.join(CSRC, "gemm_splitk_fp4.hip"), os.path.join(CSRC, "gemv_common.h")] + COMMON,
+    "splitk_reduce": [os.path.join(CSRC, "gemm_splitk_fp4.hip"), os.path.join(CSRC, "gemv_common.h")] + COMMON,
     "gemm16_": [os.path.join(CSRC, "gemm_small_fp4.hip"), os.path.join(CSRC, "gemv_common.h")] + COMMON,
 }
 
