@@ -528,7 +528,9 @@ def c5_leg(dist, backend, rank, world, dev, barrier, tokens=16):
 
                 st = par.oneshot_comm(None).status()
                 out[ar]["timeouts"] = int(st[3])  # lanes that gave up waiting for a peer (must be 0 for the figure to count)
-                par.check_oneshot(None)  # raises (-> "error" below) if any reduction of the leg timed out: its outputs were NaN
+                # collective (every rank is here: time_tokens ends in a barrier): raises on EVERY rank (-> "error" below) if a reduction
+                # of the leg timed out on ANY rank - rank 0's own status word says nothing about a peer whose outputs were NaN
+                par.check_oneshot_collective(None)
             out["allreduces_per_token"] = meta["allreduces_per_token"]  # issued inside the K-split layers (a one-rank group included)
             out["collective_ranks"] = meta["collective_ranks"]  # 1 = FP4_BENCH_FORCE_GROUP rehearsal: the calls run, no data crosses a link
             out["fp4_bytes_per_token_per_gpu"] = meta["fp4_bytes_per_token_per_gpu"]

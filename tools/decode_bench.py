@@ -255,7 +255,7 @@ def main():
         # sync point outside capture: a reduction that timed out waiting for a peer wrote NaN - the figure must not be reported
         from torch_bnb_fp4 import parallel as par
 
-        par.check_oneshot(None)
+        par.check_oneshot_collective(None)  # every rank is here; a time-out on ANY rank fails the run on every rank
     if rank == 0:
         best = t["graph_s"] or t["eager_s"]
         per_token_fp4 = meta["fp4_bytes_per_token_per_gpu"]
