@@ -185,3 +185,77 @@ def test_a_profile_without_digests_is_reported_stale(tmp_path):
     (root / "profiles" / "r04_traffic.json").write_text(json.dumps({"_method": "old", "dequant_tiles_kernel<2, 4, true>": {"traffic_bytes": 1}}))
     traffic, _, stale, why = bench.committed_traffic("dequant_tiles_kernel<2,", repo=str(root))
     assert traffic == 1 and stale is True and "no source digests" in why
+
+
+# ---- the Python surface (functions, classes, methods, parameter names, defaults) ----------------------------------------------------
+
+def _ref_params(fn: ast.FunctionDef):
+    a = fn.args
+    names = [x.arg for x in a.posonlyargs + a.args if x.arg not in ("self", "cls")]
+    defaults = {}
+    pos = [x.arg for x in a.posonlyargs + a.args]
+    for name, d in zip(pos[len(pos) - len(a.defaults):], a.defaults):
+        try:
+            defaults[name] = ast.literal_eval(d)
+        except (ValueError, SyntaxError):
+            defaults[name] = ast.unparse(d)  # an expression (torch.float16, torch.device(...)): compared as text below
+    return names, defaults
+
+
+def _our_params(obj):
+    import inspect
+
+    sig = inspect.signature(obj)
+    ps = [p for p in sig.parameters.values() if p.kind in (p.POSITIONAL_ONLY, p.POSITIONAL_OR_KEYWORD) and p.name not in ("self", "cls")]
+    return [p.name for p in ps], {p.name: p.default for p in ps if p.default is not p.empty}
+
+
+def _same_default(ref, ours) -> bool:
+    if isinstance(ref, str) and not isinstance(ours, str):  # an expression on the reference side, kept as text
+        text = ref.replace(" ", "")
+        if text.startswith("torch.device("):
+            return isinstance(ours, torch.device)  # (the reference picks cuda-if-available at import time; so do we)
+        # torch.float16, ScalarType.bfloat16.value, ...: evaluated against THIS package's names (a two-name namespace, reference text
+        # is only ever an attribute chain here - anything else fails the comparison rather than being executed blindly)
+        if not re.fullmatch(r"(torch|ScalarType)(\.\w+)+", text):
+            return False
+        obj = {"torch": torch, "ScalarType": pkg.ScalarType}[text.split(".")[0]]
+        for part in text.split(".")[1:]:
+            obj = getattr(obj, part)
+        return obj == ours
+    return ref == ours
+
+
+@needs_reference
+def test_python_surface_is_a_superset_of_the_reference_package():
+    """Every module-level function and every method of ScalarType / QuantData / TorchFP4Linear in the reference's
+    torch_bnb_fp4/__init__.py exists here under the same name, takes the same leading positional parameters BY NAME (keyword calls keep
+    working) and has the same default values; extra trailing parameters with defaults are allowed (this package's opt-in extensions)."""
+    import inspect
+
+    tree = ast.parse(open(REF_INIT).read())
+    checked = 0
+    for node in tree.body:
+        targets = []
+        if isinstance(node, ast.FunctionDef):
+            targets.append((node.name, node, getattr(pkg, node.name, None)))
+        elif isinstance(node, ast.ClassDef):
+            cls = getattr(pkg, node.name, None)
+            assert cls is not None, f"class {node.name} is missing"
+            for m in node.body:
+                if isinstance(m, ast.FunctionDef):
+                    targets.append((f"{node.name}.{m.name}", m, inspect.getattr_static(cls, m.name, None)))
+        for name, ref_fn, ours in targets:
+            assert ours is not None, f"{name} is missing"
+            if isinstance(ours, property):
+                continue  # (ScalarType.torch_dtype: a property on both sides)
+            if isinstance(ours, (classmethod, staticmethod)):
+                ours = ours.__func__
+            r_names, r_defaults = _ref_params(ref_fn)
+            o_names, o_defaults = _our_params(ours)
+            assert o_names[:len(r_names)] == r_names, f"{name}: reference parameters {r_names}, ours {o_names}"
+            assert all(n in o_defaults for n in o_names[len(r_names):]), f"{name}: an extra parameter without a default breaks reference callers"
+            for pname, rd in r_defaults.items():
+                assert pname in o_defaults and _same_default(rd, o_defaults[pname]), f"{name}({pname}=...): reference default {rd!r}, ours {o_defaults.get(pname)!r}"
+            checked += 1
+    assert checked >= 25, checked
