@@ -147,6 +147,24 @@ def measure_cell(pkg, dtype, kind):
             "split": {"three_fp4_layer_calls": _both(fp4_calls), "three_dense_nn_linear_calls": _both(dense_calls), "four_gelus": _both(gelus)},
         }
         if kind == "gemm":
+            # what one FP4 layer call of the reference's dispatch consists of, timed apart: the dequant op (allocation + one launch) and
+            # the dense GEMM on the dequantised weight (the same at::linear a dense layer pays)
+            fp4_layers = (model.in_proj, fp4_layer, model.out_proj)
+            acts = (x, h, h)
+
+            def dequants():
+                for l in fp4_layers:
+                    l.quant_data.dequantize()
+
+            weights = [l.quant_data.dequantize() for l in fp4_layers]
+
+            def linears():
+                for l, w, a in zip(fp4_layers, weights, acts):
+                    torch.nn.functional.linear(a, w, l.quant_data.bias)
+
+            cell["split"]["three_fp4_dequant_ops_alone"] = _both(dequants)
+            cell["split"]["three_dense_gemms_on_the_dequantised_weights"] = _both(linears)
+            del weights
             # the rows above take the reference's dispatch (batch > 1: dequantise, then the dense GEMM, reference __init__.py:616-617);
             # the fused small-batch kernels are opt-in because they change that dispatch
             pkg.set_small_batch_fused(model, True)
@@ -181,7 +199,8 @@ def c3_table(pkg):
         "reading": "fp4_over_dense_vs_reference_readme = [FP4 / dense on this box, the same ratio from the reference's README].  GEMV rows: the fused "
                    "GEMV beats the dense model it replaces (the README has its FP4 model ~1.19x SLOWER than dense).  GEMM rows take the reference's "
                    "dispatch (dequantise, then the dense GEMM): one more launch per FP4 layer than the dense model on a forward that is host-bound - "
-                   "`split` shows every FP4 call costing an at::linear like dense's plus the dequant launch - so they sit somewhat above dense, as "
+                   "`split` shows every FP4 call costing an at::linear like dense's (three_dense_gemms_on_the_dequantised_weights) plus the dequant "
+                   "op's allocation and launch (three_fp4_dequant_ops_alone) - so they sit somewhat above dense, as "
                    "they do in the README (1.24-1.36x there); the opt-in fused small-batch kernels (fp16 / bf16) bring those rows below dense",
     }
 
