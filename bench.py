@@ -596,7 +596,7 @@ def c3_leg(pkg):
     import sanity_bench as sb
 
     t0 = time.perf_counter()
-    table = sb.c3_table(pkg)
+    table = sb.c3_table(pkg, verbose=False)  # (the prose that explains the table: tools/sanity_bench.py, profiles/r05_c3_sanity_mlp.json)
     table["leg_seconds"] = round(time.perf_counter() - t0, 1)
     return table
 
@@ -1259,13 +1259,9 @@ def main():
             box_yardsticks(rf, M * K // 2 + 4 * (M * K // BLOCKSIZE), M * K * 2, bs_, st_)
             if "roofline_quantize" in line:  # reads the bf16 weight, writes the packed bytes + scales
                 box_yardsticks(line["roofline_quantize"], M * K * 2, M * K // 2 + 4 * (M * K // BLOCKSIZE), bs_, st_)
-            rf["box_stream_note"] = ("tools/stream_probe.hip: the dequant kernel's access geometry without arithmetic (write only, read only, copy, a bare "
-                                     "1-read : 4-write mix without and with the kernel's loads / barrier / stores phases), per 32 MiB launch like the headline "
-                                     "and as one launch over the stack of R.  box_serial_rw_estimate_gbps = bytes / (bytes written / write_only + bytes read / "
-                                     "read_only) - reading and writing back to back at the box's bare rates - from the per-launch probes, from the stack "
-                                     "probes, and from the better of the two per direction (`best_of_both`: the only one of the three that is a ceiling; the "
-                                     "per-launch read probe is launch-limited, so a kernel that overlaps its reads with its writes can exceed that estimate). "
-                                     "`frac` stays against the 8 TB/s spec")
+            rf["box_stream_note"] = ("tools/stream_probe.hip: the dequant kernel's access geometry without arithmetic, per 32 MiB launch and over the stack of R; "
+                                     "box_serial_rw_estimate_gbps = bytes / (written / write_only + read / read_only); `best_of_both` (better bare rate per "
+                                     "direction) is the one meant as a ceiling; `frac` stays against the 8 TB/s spec (DESIGN.md section 3)")
         if "dequant_plus_hipblaslt_gemv_us" in extra:
             line["fused_gemv_speedup_vs_dequant_hipblaslt"] = round(extra["dequant_plus_hipblaslt_gemv_us"] / gv_us, 2)
         if world == 1 and not args.no_cpu:

@@ -185,9 +185,10 @@ def measure_cell(pkg, dtype, kind):
     return cell
 
 
-def c3_table(pkg):
+def c3_table(pkg, verbose=True):
+    """verbose=False (bench.py's line): the same cells without the explanatory prose."""
     cells = [measure_cell(pkg, dt, kind) for dt in (torch.float32, torch.float16, torch.bfloat16) for kind in ("gemv", "gemm")]
-    return {
+    table = {
         "model": "TestModel(768, 2048, 4, 64), seeds 10: 3 FP4 layers + 3 applications of a dense 2048x2048 nn.Linear + 4 GELUs (SURVEY 0.2-11)",
         "reference_readme_gpu": README_GPU,
         "method": "eager: median of 5 x (300 forwards, one synchronise) / 300, like Timer's blocks; graph: HIP events around 40 back-to-back "
@@ -203,6 +204,10 @@ def c3_table(pkg):
                    "op's allocation and launch (three_fp4_dequant_ops_alone) - so they sit somewhat above dense, as "
                    "they do in the README (1.24-1.36x there); the opt-in fused small-batch kernels (fp16 / bf16) bring those rows below dense",
     }
+    if not verbose:
+        table["method"] = "eager: median of 5 x (300 forwards, one synchronise) / 300; graph: HIP events around 40 back-to-back replays; split: same run"
+        del table["reading"]
+    return table
 
 
 def check(pkg, dtype):
