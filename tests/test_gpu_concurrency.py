@@ -12,6 +12,7 @@ FP4_ERR_INVALID_ARGUMENT in every iteration, and no other thread may ever see an
 The reference serialises on the GIL and the legacy default stream (/root/reference/csrc/gemv_fp4_optimized.cu:266, SURVEY 0.2-8);
 this boundary promises more, so it is tested here rather than asserted in a comment."""
 import ctypes
+import os
 import threading
 
 import numpy as np
@@ -24,7 +25,7 @@ from oracle import c_oracle
 
 pytestmark = pytest.mark.gpu
 BS = 64
-ITERS = 200
+ITERS = int(os.environ.get("FP4_CONCURRENCY_ITERS", "200"))  # (a soak run: FP4_CONCURRENCY_ITERS=5000)
 
 
 def _jobs():
