@@ -115,3 +115,37 @@ def test_small_batch_at_2_pow_32_elements(huge):
             exact_d = _device_f64_product(P, A, x64, M, K, table_d)
             scale_d = _device_f64_product(P, A, x64.abs(), M, K, table_d, magnitudes=True)
             _check(out[b], exact_d, scale_d, dtype, f"gemm_small rows={B} row {b}")
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_quantiser_and_dequant_past_2_to_the_31_elements(dtype):
+    """The quantiser (both kernels) and the dequant on 2^31 + 2^22 elements: element offsets past 2^31, byte offsets of the f32 input past
+    2^33.  Blocks are independent, so a weight made of one 2^20-element pattern repeated must quantise to that pattern's packed bytes and
+    scales repeated - and the pattern's own result is held against the oracle, bit for bit.  The dequant of the huge result must likewise
+    be the pattern's dequant repeated (checked by comparing every repetition on the device)."""
+    from oracle import fp4_oracle as o
+
+    free, _ = torch.cuda.mem_get_info()
+    unit, reps = 1 << 20, (1 << 11) + 4
+    n = unit * reps
+    if free < (n * (4 + torch.empty((), dtype=dtype).element_size()) + (4 << 30)):
+        pytest.skip("needs ~24 GiB of free device memory")
+    rng = np.random.default_rng(11)
+    pat = (rng.standard_normal(unit) * 10.0 ** rng.uniform(-2, 1, unit)).astype(np.float32)
+    pat[64:128] = 0.0
+    pat_t = torch.from_numpy(pat).to(dtype).to(dev())
+    want_p, want_a = o.quantize_fp4(pat_t.float().cpu().numpy(), BS)
+    w = pat_t.repeat(reps)
+    assert w.numel() == n and n > (1 << 31)
+    for variant in (4, 1002, 0):  # persistent kernel, tiles kernel, the library's choice
+        hipabi.set_variant("quantize", variant)
+        packed, absmax = hipabi.quantize(w, BS)
+        p2, a2 = packed.view(reps, unit // 2), absmax.view(reps, unit // BS)
+        assert np.array_equal(p2[0].cpu().numpy(), want_p) and np.array_equal(a2[0].cpu().numpy(), want_a), variant
+        assert bool((p2 == p2[0]).all()) and bool((a2 == a2[0]).all()), variant  # every repetition, the ones past 2^31 included
+    hipabi.set_variant("quantize", 0)
+    del w
+    out = hipabi.dequantize(packed, absmax, BS, n, torch.bfloat16)
+    o2 = out.view(reps, unit).view(torch.int16)
+    want = o.dequantize(want_p, want_a, BS, unit, "bfloat16", "codebook")
+    assert np.array_equal(o2[0].cpu().numpy().view(np.uint16), want) and bool((o2 == o2[0]).all())
