@@ -119,7 +119,8 @@ FP4_HIP_API int fp4_hip_gemv_fused(const void *x, const uint8_t *packed, const f
  *   out[b][r] = T( sum_k x[b][k] * code[nibble(r,k)] * absmax[(r*K+k)/blocksize] + bias[r] )
  * x is T[B,K] row-major, out T[B,M]; f32 accumulation, ONE rounding, bias added in f32 first (what the
  * reference's batch > 1 path, dequant + F.linear, does - torch_bnb_fp4/__init__.py:423-436,616-617 - without
- * writing and re-reading the M*K dequantised weight).  16-bit dtypes only.  Two kernels: a matrix-core one
+ * writing and re-reading the M*K dequantised weight).  16-bit dtypes; f32 activations are covered up to 8 rows as B launches of the f32
+ * GEMV (each row bit-identical to fp4_hip_gemv; FP4_ERR_UNSUPPORTED above that and for the gated epilogue).  Two kernels: a matrix-core one
  * (v_mfma_f32_16x16x32; blocksize 64, K % 512 == 0; any B <= 16) and a VALU one (B <= 8; K % 32 == 0, K <= 16384,
  * less for larger B; power-of-two blocksize >= 32 dividing K).  Returns FP4_ERR_UNSUPPORTED for shapes neither
  * covers, so the caller can fall back to dequant + GEMM.  17..64 rows (blocksize 64, K % 64 == 0; and 1..16 rows where

@@ -485,3 +485,24 @@ def test_gemv_beyond_32bit_weight_indices():
         assert (np.abs(got - exact) <= 2.0**-8 * 1.01 * np.abs(exact) + 1e-5 * scale).all(), r0
     del packed, absmax, y
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("M,K,B", [(4096, 4096, 2), (2048, 768, 8), (64, 2048, 5), (300, 1000, 3)])
+def test_small_batch_f32_rows_are_the_f32_gemv_row_by_row(M, K, B):
+    """f32 activations in fp4_hip_gemm_small / _fused: up to 8 rows, each computed by the f32 GEMV kernel - bit-identical to the
+    single-row call (with bias, with residual), inside the float64 bar, FP4_ERR_UNSUPPORTED above 8 rows and for the gated epilogue."""
+    c = case(M, K)
+    x_t, b_t, exact, scale = c.rows(B, 91, torch.float32)
+    got = hipabi.gemm_small(x_t, c.P, c.A, M, K, 64, b_t)
+    assert got.shape == (B, M) and got.dtype == torch.float32
+    for b in range(B):
+        assert torch.equal(got[b], hipabi.gemv(x_t[b].contiguous(), c.P, c.A, M, K, 64, b_t)), b
+    assert_within_bar(got, exact, scale, torch.float32)
+    res = torch_values(np.random.default_rng(7).standard_normal((B, M)).astype(np.float32), torch.float32)
+    fused = hipabi.gemm_small_fused(x_t, c.P, c.A, M, K, 64, b_t, res)
+    for b in range(B):
+        assert torch.equal(fused[b], hipabi.gemv_fused(x_t[b].contiguous(), c.P, c.A, M, K, 64, b_t, res[b].contiguous())), b
+    nine = torch.zeros(9, K, dtype=torch.float32, device=dev())
+    assert hipabi.gemm_small(nine, c.P, c.A, M, K, 64, expect_ok=False) == hipabi.ERR_UNSUPPORTED and "dequant + GEMM" in hipabi.last_error()
+    if M % 2 == 0:
+        assert hipabi.gemm_small_fused(x_t, c.P, c.A, M, K, 64, None, None, hipabi.EPILOGUE_SILU_MUL_PAIRS, expect_ok=False) == hipabi.ERR_UNSUPPORTED

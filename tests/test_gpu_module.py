@@ -480,6 +480,16 @@ def test_set_small_batch_fused_switches_the_batch_path():
         again = model(x)
     assert torch.equal(again, ref)
     assert torch.allclose(fused.float(), ref.float(), rtol=2e-2, atol=2e-2)
+    # f32 activations: 2..8 rows go to the f32 GEMV row by row; both paths compute x @ dequant_f32(W)^T + b in f32
+    m32 = torch.nn.Sequential(torch.nn.Linear(512, 1024), torch.nn.SiLU(), torch.nn.Linear(1024, 512))
+    m32 = pkg.recursively_replace_with_fp4_linear(m32, as_dtype=torch.float32, device=dev())
+    x32 = torch.randn(2, 512, device=dev())
+    with torch.inference_mode():
+        ref32 = m32(x32)
+        pkg.set_small_batch_fused(m32, True)
+        fused32 = m32(x32)
+        assert torch.equal(fused32[:1], m32(x32[:1]))  # ... and each row is exactly the single-token result
+    assert fused32.dtype == torch.float32 and torch.allclose(fused32, ref32, rtol=1e-4, atol=1e-4)
 
 
 

@@ -148,6 +148,13 @@ def test_small_batch_opt_in(fake):
     fake.calls.clear()
     qd.forward(torch.randn(1, 128).to(torch.bfloat16))  # single token is still the GEMV
     assert fake.calls == ["gemv_fp4_bias"]
+    # f32 activations: up to 8 rows (one f32 GEMV launch per row inside the op), the reference path above that
+    qd32, _, _ = make_quant_data(64, 128, small_batch_fused=True)
+    fake.calls.clear()
+    assert qd32.forward(torch.randn(8, 128)).shape == (8, 64) and fake.calls == ["gemm_small_fp4"]
+    fake.calls.clear()
+    qd32.forward(torch.randn(9, 128))
+    assert fake.calls == ["qlinear_codebook_bias"]
 
 
 def test_fused_layers_dispatch_and_fall_back(fake, monkeypatch):

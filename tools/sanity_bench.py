@@ -202,7 +202,7 @@ def c3_table(pkg, verbose=True):
                    "dispatch (dequantise, then the dense GEMM): one more launch per FP4 layer than the dense model on a forward that is host-bound - "
                    "`split` shows every FP4 call costing an at::linear like dense's (three_dense_gemms_on_the_dequantised_weights) plus the dequant "
                    "op's allocation and launch (three_fp4_dequant_ops_alone) - so they sit somewhat above dense, as "
-                   "they do in the README (1.24-1.36x there); the opt-in fused small-batch kernels (fp16 / bf16) bring those rows below dense",
+                   "they do in the README (1.24-1.36x there); the opt-in fused small-batch path (matrix-core kernels for fp16 / bf16, one f32 GEMV per row for f32) brings those rows below dense",
     }
     if not verbose:
         table["method"] = "eager: median of 5 x (300 forwards, one synchronise) / 300; graph: HIP events around 40 back-to-back replays; split: same run"

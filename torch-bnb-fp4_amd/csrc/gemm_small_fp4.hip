@@ -743,6 +743,30 @@ int gemm_small_entry(const void *x, const uint8_t *packed, const float *absmax, 
         return FP4_ERR_INVALID_ARGUMENT;
     }
     const int64_t M_out = (mode & kModeSiluMulPairs) ? M / 2 : M;
+    if (dtype == FP4_DTYPE_F32) {
+        // f32 activations (the reference's sanity harness; models run 16-bit): no matrix-core kernel and none needed - up to 8 rows run
+        // as B launches of the f32 GEMV, each streaming the weight once (B x 9.45 MB against the 76 MB a dequantised 4096 x 4096 f32
+        // weight costs to write and read back) and each bit-identical to the single-row call; bias and residual as the GEMV applies them
+        // (in f32 "T(T(sum) + bias)" is the one f32 addition F.linear does).  More rows, or the gated epilogue: the caller's dequant + GEMM.
+        if (B > 8 || (mode & kModeSiluMulPairs)) {
+            set_error("fp4_hip_gemm_small: f32 activations are covered up to 8 rows without the gate|up epilogue (got B=%lld); "
+                      "use dequant + GEMM", (long long)B);
+            return FP4_ERR_UNSUPPORTED;
+        }
+        if (M == 0) return FP4_OK;
+        if (!x || !out) {
+            set_error("fp4_hip_gemm_small: null pointer");
+            return FP4_ERR_INVALID_ARGUMENT;
+        }
+        for (int64_t b = 0; b < B; ++b) {
+            const int rc = fp4_hip_gemv_fused(static_cast<const float *>(x) + size_t(b) * size_t(K), packed, absmax, bias,
+                                              residual ? static_cast<const float *>(residual) + size_t(b) * size_t(M) : nullptr,
+                                              static_cast<float *>(out) + size_t(b) * size_t(M), M, K, blocksize, FP4_DTYPE_F32,
+                                              FP4_EPILOGUE_NONE, stream);
+            if (rc != FP4_OK) return rc;
+        }
+        return FP4_OK;
+    }
     if (B > 16) {
         if (dtype != FP4_DTYPE_F16 && dtype != FP4_DTYPE_BF16) {
             set_error("fp4_hip_gemm_small: more than 16 rows need a 16-bit dtype, got %d", dtype);

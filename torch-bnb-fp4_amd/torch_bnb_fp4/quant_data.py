@@ -16,7 +16,7 @@ everything else (batch or seq > 1)    ``qlinear`` = dequant + F.linear   (:616-6
 Two extensions.  ``fuse_bias`` (ON by default) folds the post-GEMV ``out += bias`` into the kernel epilogue: the table above
 still holds and the result is bit-identical (``T(T(sum) + bias)``), there is just one launch fewer; ``fuse_bias=False`` runs the
 reference's two-step sequence literally.  ``small_batch_fused`` (OFF by default, because it changes the table's last row) sends
-2..128 activation rows to the fused small-batch kernels instead of dequant + GEMM.
+2..128 activation rows (f32 activations: 2..8, one f32 GEMV launch per row) to the fused small-batch kernels instead of dequant + GEMM.
 """
 from __future__ import annotations
 
@@ -146,7 +146,9 @@ class QuantData:
             return self.forward(A)
         # everything that is not a 2-D / 3-D single token with K % blocksize == 0 (:593-594, :614-617)
         rows = total // K
-        if (self.small_batch_fused and 2 <= rows <= 128 and A.dtype in (torch.float16, torch.bfloat16)
-                and ((self.blocksize == 64 and K % 64 == 0) or (rows <= 8 and K % self.blocksize == 0 and K % 32 == 0 and K <= 4096))):
+        if self.small_batch_fused and 2 <= rows <= 128 and (
+                (A.dtype in (torch.float16, torch.bfloat16)
+                 and ((self.blocksize == 64 and K % 64 == 0) or (rows <= 8 and K % self.blocksize == 0 and K % 32 == 0 and K <= 4096)))
+                or (A.dtype == torch.float32 and rows <= 8 and K % self.blocksize == 0)):  # f32: one f32 GEMV per row, up to 8 rows
             return ext.gemm_small_fp4(A.contiguous(), self.A.t(), self.absmax, self.blocksize, self._shape_list, self.bias)
         return self.qlinear(A)
