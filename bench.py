@@ -781,7 +781,8 @@ def committed_traffic(prefix: str, profiles_dir: str | None = None, repo: str = 
     import glob
     import re
 
-    sys.path.insert(0, os.path.join(REPO, "tools"))
+    if os.path.join(REPO, "tools") not in sys.path:
+        sys.path.insert(0, os.path.join(REPO, "tools"))
     import source_digest
 
     def order(path):
