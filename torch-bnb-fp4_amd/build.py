@@ -133,7 +133,7 @@ def build_torch_ext(force: bool = False) -> str:
     _run([_hipcc(), "-O2", "-std=c++17", "-fPIC", "-shared", "-DTORCH_EXTENSION_NAME=torch_bnb_fp4_ext",
           "-DTORCH_API_INCLUDE_EXTENSION_H", f"-D_GLIBCXX_USE_CXX11_ABI={abi}", "-DUSE_ROCM", "-Wno-unused-parameter",
           *inc, src, "-o", EXT_LIB, f"-L{torch_lib}", "-lc10", "-lc10_hip", "-ltorch_cpu", "-ltorch", "-ltorch_hip",
-          "-ltorch_python", f"-L{LIB_DIR}", "-ltorch_bnb_fp4_hip", "-Wl,-rpath,$ORIGIN/torch_bnb_fp4/lib",
+          "-ltorch_python", "-lhipblaslt", "-lamdhip64", f"-L{LIB_DIR}", "-ltorch_bnb_fp4_hip", "-Wl,-rpath,$ORIGIN/torch_bnb_fp4/lib",
           f"-Wl,-rpath,{torch_lib}"])
     return EXT_LIB
 

@@ -15,12 +15,18 @@
 // Extra exports (not in the reference): gemv_fp4_bias, gemv_fp4_fused, comm_* / allreduce_oneshot, gemm_small_fp4, gemv_fp4_partial, quantize_fp4, set_kernel_variant, code_table.
 #include <c10/core/DeviceGuard.h>
 #include <c10/hip/HIPStream.h>
+#include <hip/hip_runtime_api.h>
+#include <hipblaslt/hipblaslt.h>
 #include <torch/extension.h>
 
+#include <atomic>
 #include <cstdint>
+#include <cstdlib>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <tuple>
+#include <unordered_map>
 #include <vector>
 
 #include "torch_bnb_fp4_hip.h"
@@ -108,6 +114,173 @@ torch::Tensor dequantize_fp4_codebook(torch::Tensor A, torch::Tensor absmax, tor
     return out;
 }
 
+// ---- the dense GEMM of the batch > 1 path: hipBLASLt, called directly ------------------------------------------------------------
+// The reference's batch > 1 path is dequant + torch::nn::functional::linear (csrc/torch_fp4.cpp:64-103).  On ROCm every torch GEMM
+// entry point (linear, addmm, mm, with or without bias, either BLAS backend) costs ~18.5 us of HOST time per call on this platform
+// (tools/exp_blas_host_cost.py; a trivial torch op: 4.3 us), most of it descriptor set-up and the heuristic query repeated on every
+// call - and an eager small-batch forward is host-bound, so the dequant + GEMM layer came out slower than the dense layer it replaces
+// (BASELINE config 3, `c3_sanity_mlp`).  The same library call with the descriptors, layouts and the chosen algorithm cached per
+// (device, dtype, rows, M, K, bias) costs a few microseconds.  Same maths as at::linear: x [rows, K] row-major times W [M, K]^T,
+// f32 accumulation (HIPBLAS_COMPUTE_32F, no reduced-precision f32 mode), bias through the library's epilogue, one rounding to T.
+// Anything this path does not cover - other dtypes, a bias of another dtype, no algorithm returned, the first call of a device
+// arriving under stream capture - goes to at::linear; FP4_QLINEAR_GEMM=aten (or set_qlinear_gemm("aten")) forces that route.
+std::atomic<int> g_qlinear_gemm{-1};  // -1 = not decided yet (environment), 0 = at::linear, 1 = hipBLASLt direct
+
+bool qlinear_gemm_direct() {
+    int v = g_qlinear_gemm.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char *e = std::getenv("FP4_QLINEAR_GEMM");
+        v = (e && std::string(e) == "aten") ? 0 : 1;
+        g_qlinear_gemm.store(v, std::memory_order_relaxed);
+    }
+    return v == 1;
+}
+
+std::string set_qlinear_gemm(const std::string &which) {
+    TORCH_CHECK(which == "hipblaslt" || which == "aten", "set_qlinear_gemm: 'hipblaslt' or 'aten', got '", which, "'");
+    const bool was = qlinear_gemm_direct();
+    g_qlinear_gemm.store(which == "hipblaslt" ? 1 : 0, std::memory_order_relaxed);
+    return was ? "hipblaslt" : "aten";
+}
+
+struct LtPlan {
+    hipblasLtMatmulDesc_t desc = nullptr;
+    hipblasLtMatrixLayout_t a = nullptr, b = nullptr, c = nullptr;
+    hipblasLtMatmulAlgo_t algo{};
+    size_t workspace = 0;
+    bool usable = false;
+    ~LtPlan() {
+        if (a) hipblasLtMatrixLayoutDestroy(a);
+        if (b) hipblasLtMatrixLayoutDestroy(b);
+        if (c) hipblasLtMatrixLayoutDestroy(c);
+        if (desc) hipblasLtMatmulDescDestroy(desc);
+    }
+};
+
+struct LtKey {
+    int device, dtype, bias;
+    int64_t rows, M, K;
+    bool operator==(const LtKey &o) const {
+        return device == o.device && dtype == o.dtype && bias == o.bias && rows == o.rows && M == o.M && K == o.K;
+    }
+};
+struct LtKeyHash {
+    size_t operator()(const LtKey &k) const {
+        size_t h = std::hash<int64_t>()(k.rows * 1000003 + k.M);
+        h ^= std::hash<int64_t>()(k.K * 31 + k.dtype * 7 + k.bias * 3 + k.device) + 0x9e3779b97f4a7c15ULL + (h << 6) + (h >> 2);
+        return h;
+    }
+};
+
+// one handle per device, shared by every thread (hipblasLtMatmul is thread-safe on a handle as long as the workspaces differ)
+hipblasLtHandle_t lt_handle(int device, bool may_create) {
+    static std::mutex mu;
+    static hipblasLtHandle_t handles[64] = {};
+    if (device < 0 || device >= 64) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!handles[device] && may_create) {
+        hipblasLtHandle_t h = nullptr;
+        if (hipblasLtCreate(&h) == HIPBLAS_STATUS_SUCCESS) handles[device] = h;
+    }
+    return handles[device];
+}
+
+constexpr size_t kLtMaxWorkspace = size_t(32) << 20;
+
+// Plans are per THREAD: the bias pointer is an attribute of the matmul descriptor and is set on every call, so a descriptor must not
+// be shared by two threads launching at once (the concurrency promise of this boundary: tests/test_gpu_concurrency.py).
+LtPlan *lt_plan(hipblasLtHandle_t handle, const LtKey &key, hipDataType dt) {
+    thread_local std::unordered_map<LtKey, std::unique_ptr<LtPlan>, LtKeyHash> plans;
+    auto it = plans.find(key);
+    if (it != plans.end()) return it->second.get();
+    auto plan = std::make_unique<LtPlan>();
+    LtPlan *p = plan.get();
+    plans.emplace(key, std::move(plan));  // kept even if unusable: the failure is remembered, not retried on every call
+    // column-major view of the row-major operands: D[M, rows] = op_T(A = W as K x M, ld K) * (B = x as K x rows, ld K), ld(D) = M
+    const hipblasOperation_t opT = HIPBLAS_OP_T, opN = HIPBLAS_OP_N;
+    if (hipblasLtMatmulDescCreate(&p->desc, HIPBLAS_COMPUTE_32F, HIP_R_32F) != HIPBLAS_STATUS_SUCCESS) return p;
+    if (hipblasLtMatmulDescSetAttribute(p->desc, HIPBLASLT_MATMUL_DESC_TRANSA, &opT, sizeof(opT)) != HIPBLAS_STATUS_SUCCESS ||
+        hipblasLtMatmulDescSetAttribute(p->desc, HIPBLASLT_MATMUL_DESC_TRANSB, &opN, sizeof(opN)) != HIPBLAS_STATUS_SUCCESS)
+        return p;
+    if (key.bias) {
+        const hipblasLtEpilogue_t epi = HIPBLASLT_EPILOGUE_BIAS;
+        const int32_t bias_type = static_cast<int32_t>(dt);
+        if (hipblasLtMatmulDescSetAttribute(p->desc, HIPBLASLT_MATMUL_DESC_EPILOGUE, &epi, sizeof(epi)) != HIPBLAS_STATUS_SUCCESS ||
+            hipblasLtMatmulDescSetAttribute(p->desc, HIPBLASLT_MATMUL_DESC_BIAS_DATA_TYPE, &bias_type, sizeof(bias_type)) !=
+                HIPBLAS_STATUS_SUCCESS)
+            return p;
+    }
+    if (hipblasLtMatrixLayoutCreate(&p->a, dt, uint64_t(key.K), uint64_t(key.M), key.K) != HIPBLAS_STATUS_SUCCESS ||
+        hipblasLtMatrixLayoutCreate(&p->b, dt, uint64_t(key.K), uint64_t(key.rows), key.K) != HIPBLAS_STATUS_SUCCESS ||
+        hipblasLtMatrixLayoutCreate(&p->c, dt, uint64_t(key.M), uint64_t(key.rows), key.M) != HIPBLAS_STATUS_SUCCESS)
+        return p;
+    hipblasLtMatmulPreference_t pref = nullptr;
+    if (hipblasLtMatmulPreferenceCreate(&pref) != HIPBLAS_STATUS_SUCCESS) return p;
+    const uint64_t max_ws = kLtMaxWorkspace;
+    hipblasLtMatmulHeuristicResult_t result{};
+    int found = 0;
+    if (hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &max_ws, sizeof(max_ws)) == HIPBLAS_STATUS_SUCCESS &&
+        hipblasLtMatmulAlgoGetHeuristic(handle, p->desc, p->a, p->b, p->c, p->c, pref, 1, &result, &found) == HIPBLAS_STATUS_SUCCESS &&
+        found > 0 && result.state == HIPBLAS_STATUS_SUCCESS && result.workspaceSize <= kLtMaxWorkspace) {
+        p->algo = result.algo;
+        p->workspace = result.workspaceSize;
+        p->usable = true;
+    }
+    hipblasLtMatmulPreferenceDestroy(pref);
+    return p;
+}
+
+// out [.., M] = x [.., K] @ weight[M, K]^T (+ bias) through the cached hipBLASLt plan; false = not covered (the caller uses at::linear)
+bool lt_linear(const torch::Tensor &x, const torch::Tensor &weight, const c10::optional<torch::Tensor> &bias, torch::Tensor &out) {
+    hipDataType dt;
+    switch (x.scalar_type()) {
+        case torch::kBFloat16: dt = HIP_R_16BF; break;
+        case torch::kFloat16: dt = HIP_R_16F; break;
+        case torch::kFloat32: dt = HIP_R_32F; break;
+        default: return false;
+    }
+    const int64_t K = weight.size(1), M = weight.size(0);
+    if (x.dim() < 1 || x.size(-1) != K || !x.is_cuda() || x.device() != weight.device() || weight.scalar_type() != x.scalar_type() ||
+        K <= 0 || M <= 0)
+        return false;
+    const int64_t rows = x.numel() / K;
+    if (rows <= 0 || rows > (int64_t(1) << 30)) return false;
+    if (bias.has_value() && (!bias->is_cuda() || bias->device() != x.device() || bias->scalar_type() != x.scalar_type() ||
+                             bias->numel() != M || !bias->is_contiguous()))
+        return false;
+    const int device = x.device().index();
+    hipStream_t stream = c10::hip::getCurrentHIPStream(device).stream();
+    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(stream, &capturing);
+    // creating the library handle may allocate: never for the first time under stream capture
+    hipblasLtHandle_t handle = lt_handle(device, capturing == hipStreamCaptureStatusNone);
+    if (!handle) return false;
+    LtPlan *plan = lt_plan(handle, LtKey{device, int(dt), bias.has_value() ? 1 : 0, rows, M, K}, dt);
+    if (!plan->usable) return false;
+    const torch::Tensor xc = x.is_contiguous() ? x : x.contiguous();
+    auto shape = x.sizes().vec();
+    shape.back() = M;
+    out = torch::empty(shape, x.options());
+    torch::Tensor ws;
+    void *ws_ptr = nullptr;
+    if (plan->workspace > 0) {  // from torch's caching allocator: stream-ordered, no synchronisation, fine under graph capture
+        ws = torch::empty({int64_t(plan->workspace)}, x.options().dtype(torch::kUInt8));
+        ws_ptr = ws.data_ptr();
+    }
+    if (bias.has_value()) {
+        const void *bp = bias->data_ptr();
+        if (hipblasLtMatmulDescSetAttribute(plan->desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bp, sizeof(bp)) != HIPBLAS_STATUS_SUCCESS) return false;
+    }
+    const float alpha = 1.0f, beta = 0.0f;
+    const hipblasStatus_t st = hipblasLtMatmul(handle, plan->desc, &alpha, weight.data_ptr(), plan->a, xc.data_ptr(), plan->b, &beta,
+                                               out.data_ptr(), plan->c, out.data_ptr(), plan->c, &plan->algo, ws_ptr, plan->workspace, stream);
+    if (st != HIPBLAS_STATUS_SUCCESS) {
+        plan->usable = false;  // do not try this shape again
+        return false;
+    }
+    return true;
+}
+
 torch::Tensor qlinear_impl(const torch::Tensor &A_in, const torch::Tensor &A, const torch::Tensor &absmax, int M, int N,
                            int blocksize, int table, const c10::optional<torch::Tensor> &bias) {
     check_gpu_contiguous(A, "A");
@@ -115,6 +288,11 @@ torch::Tensor qlinear_impl(const torch::Tensor &A_in, const torch::Tensor &A, co
     torch::Tensor weight = torch::empty({M, N}, A_in.options());
     // the GEMM below reads the weight straight back: keep it in L2 / Infinity Cache (plain stores)
     dequant_into(A, absmax, weight, blocksize, int64_t(M) * N, table, FP4_DEQUANT_KEEP_CACHED);
+    if (qlinear_gemm_direct()) {
+        c10::DeviceGuard guard(A_in.device());
+        torch::Tensor out;
+        if (lt_linear(A_in, weight, bias, out)) return out;
+    }
     return bias.has_value() ? at::linear(A_in, weight, *bias) : at::linear(A_in, weight);
 }
 
@@ -451,6 +629,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("quantize_fp4", &quantize_fp4, "blockwise FP4 quantiser: (W, blocksize) -> (packed, absmax)");
     m.def("code_table", &code_table, "16-entry code table as a CPU float tensor");
     m.def("set_kernel_variant", &set_kernel_variant, "benchmark hook: select a kernel geometry");
+    m.def("set_qlinear_gemm", &set_qlinear_gemm,
+          "which dense GEMM the qlinear* ops call after the dequant: 'hipblaslt' (direct, cached plans; default) or 'aten' (at::linear); "
+          "returns the previous setting");
     m.attr("EPILOGUE_NONE") = (int)FP4_EPILOGUE_NONE;
     m.attr("EPILOGUE_SILU_MUL_PAIRS") = (int)FP4_EPILOGUE_SILU_MUL_PAIRS;
     m.attr("abi_version") = fp4_hip_abi_version();
