@@ -147,8 +147,9 @@ def measure_cell(pkg, dtype, kind):
             "split": {"three_fp4_layer_calls": _both(fp4_calls), "three_dense_nn_linear_calls": _both(dense_calls), "four_gelus": _both(gelus)},
         }
         if kind == "gemm":
-            # what one FP4 layer call of the reference's dispatch consists of, timed apart: the dequant op (allocation + one launch) and
-            # the dense GEMM on the dequantised weight (the same at::linear a dense layer pays)
+            # what one FP4 layer call of the reference's dispatch consists of, timed apart: the dequant op (allocation + one launch), and -
+            # for comparison - the dense GEMM on the dequantised weight through F.linear, i.e. what the layer call WOULD pay for its GEMM
+            # if the extension went through at::linear like the reference (it calls hipBLASLt directly: csrc/torch_ext.cpp, lt_linear)
             fp4_layers = (model.in_proj, fp4_layer, model.out_proj)
             acts = (x, h, h)
 
@@ -163,7 +164,7 @@ def measure_cell(pkg, dtype, kind):
                     torch.nn.functional.linear(a, w, l.quant_data.bias)
 
             cell["split"]["three_fp4_dequant_ops_alone"] = _both(dequants)
-            cell["split"]["three_dense_gemms_on_the_dequantised_weights"] = _both(linears)
+            cell["split"]["three_f_linear_calls_on_the_dequantised_weights"] = _both(linears)
             del weights
             # the rows above take the reference's dispatch (batch > 1: dequantise, then the dense GEMM, reference __init__.py:616-617);
             # the fused small-batch kernels are opt-in because they change that dispatch
@@ -199,10 +200,11 @@ def c3_table(pkg, verbose=True):
         "fp4_over_dense_vs_reference_readme": {f"{c['dtype']}_{c['kind']}": [c["fp4_over_dense"], c["reference_readme_fp4_over_dense"]] for c in cells},
         "reading": "fp4_over_dense_vs_reference_readme = [FP4 / dense on this box, the same ratio from the reference's README].  GEMV rows: the fused "
                    "GEMV beats the dense model it replaces (the README has its FP4 model ~1.19x SLOWER than dense).  GEMM rows take the reference's "
-                   "dispatch (dequantise, then the dense GEMM): one more launch per FP4 layer than the dense model on a forward that is host-bound - "
-                   "`split` shows every FP4 call costing an at::linear like dense's (three_dense_gemms_on_the_dequantised_weights) plus the dequant "
-                   "op's allocation and launch (three_fp4_dequant_ops_alone) - so they sit somewhat above dense, as "
-                   "they do in the README (1.24-1.36x there); the opt-in fused small-batch path (matrix-core kernels for fp16 / bf16, one f32 GEMV per row for f32) brings those rows below dense",
+                   "dispatch (dequantise, then the dense GEMM) on a forward that is host-bound: through at::linear every FP4 call would cost a dense "
+                   "call (three_f_linear_calls_on_the_dequantised_weights) PLUS the dequant op (three_fp4_dequant_ops_alone) and the model sat at "
+                   "1.08-1.13x dense (README: 1.24-1.36x); the extension calls hipBLASLt directly with cached plans instead, which brings the three FP4 "
+                   "layer calls below three dense nn.Linear calls and the forward level with the dense model; the opt-in fused small-batch path "
+                   "(matrix-core kernels for fp16 / bf16, one f32 GEMV per row for f32) goes well below it",
     }
     if not verbose:
         table["method"] = "eager: median of 5 x (300 forwards, one synchronise) / 300; graph: HIP events around 40 back-to-back replays; split: same run"

@@ -250,11 +250,14 @@ bool lt_linear(const torch::Tensor &x, const torch::Tensor &weight, const c10::o
         return false;
     const int device = x.device().index();
     hipStream_t stream = c10::hip::getCurrentHIPStream(device).stream();
-    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
-    (void)hipStreamIsCapturing(stream, &capturing);
-    // creating the library handle may allocate: never for the first time under stream capture
-    hipblasLtHandle_t handle = lt_handle(device, capturing == hipStreamCaptureStatusNone);
-    if (!handle) return false;
+    hipblasLtHandle_t handle = lt_handle(device, false);
+    if (!handle) {  // first GEMM on this device: creating the library handle may allocate, so never under stream capture
+        hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(stream, &capturing);
+        if (capturing != hipStreamCaptureStatusNone) return false;
+        handle = lt_handle(device, true);
+        if (!handle) return false;
+    }
     LtPlan *plan = lt_plan(handle, LtKey{device, int(dt), bias.has_value() ? 1 : 0, rows, M, K}, dt);
     if (!plan->usable) return false;
     const torch::Tensor xc = x.is_contiguous() ? x : x.contiguous();
