@@ -251,7 +251,8 @@ bool lt_linear(const torch::Tensor &x, const torch::Tensor &weight, const c10::o
     const int device = x.device().index();
     hipStream_t stream = c10::hip::getCurrentHIPStream(device).stream();
     hipblasLtHandle_t handle = lt_handle(device, false);
-    if (!handle) {  // first GEMM on this device: creating the library handle may allocate, so never under stream capture
+    if (!handle) {  // first GEMM on this device: creating the library handle is not permitted under stream capture - hand the call to
+                    // at::linear, which (measured) fails there exactly as a dense torch GEMM does: warm up before capturing, as always
         hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
         (void)hipStreamIsCapturing(stream, &capturing);
         if (capturing != hipStreamCaptureStatusNone) return false;
