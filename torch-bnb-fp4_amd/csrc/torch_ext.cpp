@@ -185,7 +185,7 @@ hipblasLtHandle_t lt_handle(int device, bool may_create) {
     return handles[device];
 }
 
-constexpr size_t kLtMaxWorkspace = size_t(32) << 20;
+constexpr size_t kLtMaxWorkspace = size_t(76) << 20;  // what torch itself grants hipBLASLt on gfx94x / gfx95x: the heuristic then picks from the same algorithms
 
 // Plans are per THREAD: the bias pointer is an attribute of the matmul descriptor and is set on every call, so a descriptor must not
 // be shared by two threads launching at once (the concurrency promise of this boundary: tests/test_gpu_concurrency.py).
