@@ -193,6 +193,8 @@ LtPlan *lt_plan(hipblasLtHandle_t handle, const LtKey &key, hipDataType dt) {
     thread_local std::unordered_map<LtKey, std::unique_ptr<LtPlan>, LtKeyHash> plans;
     auto it = plans.find(key);
     if (it != plans.end()) return it->second.get();
+    // (a prefill loop over ever-changing sequence lengths must not grow this without bound: plans are cheap to rebuild, ~0.1 ms each)
+    if (plans.size() >= 4096) plans.clear();
     auto plan = std::make_unique<LtPlan>();
     LtPlan *p = plan.get();
     plans.emplace(key, std::move(plan));  // kept even if unusable: the failure is remembered, not retried on every call
