@@ -4,15 +4,16 @@
 // csrc/torch_fp4.cpp:125-139): ScalarType + dequantize_fp4, dequantize_fp4_codebook, gemv_fp4,
 // qlinear, qlinear_bias, qlinear_codebook, qlinear_codebook_bias, with the same positional
 // signatures, argument meaning and error behaviour (RuntimeError on a non-GPU / non-contiguous
-// tensor, TypeError on a bad enum).  PyTorch is plumbing only: it owns device memory, the current
-// stream and the batch>1 GEMM (at::linear -> hipBLASLt/rocBLAS); every FP4 kernel is behind the
-// C ABI.  Differences from the reference, all deliberate:
+// tensor, TypeError on a bad enum).  PyTorch is plumbing only: it owns device memory and the current
+// stream; the batch>1 GEMM is a plain library GEMM on hipBLASLt, called directly with cached plans
+// (lt_linear below; at::linear is its fallback); every FP4 kernel is behind the C ABI.
+// Differences from the reference, all deliberate:
 //   * launches go to the CURRENT torch stream under a device guard (the reference uses the legacy
 //     default stream and no guard, csrc/dequant_fp4_optimized.cu:176, csrc/gemv_fp4_optimized.cu:266);
 //   * launch / dtype failures raise instead of printf (csrc/dequant_fp4_optimized.cu:48-53,201-203);
 //   * qlinear_codebook* dequantise all M*N elements (the reference passes the BYTE count,
 //     csrc/torch_fp4.cpp:90,101, leaving half of the weight uninitialised).
-// Extra exports (not in the reference): gemv_fp4_bias, gemv_fp4_fused, comm_* / allreduce_oneshot, gemm_small_fp4, gemv_fp4_partial, quantize_fp4, set_kernel_variant, code_table.
+// Extra exports (not in the reference): gemv_fp4_bias, gemv_fp4_fused, comm_* / allreduce_oneshot, gemm_small_fp4, gemv_fp4_partial, quantize_fp4, set_kernel_variant, set_qlinear_gemm, code_table.
 #include <c10/core/DeviceGuard.h>
 #include <c10/hip/HIPStream.h>
 #include <hip/hip_runtime_api.h>
